@@ -1,0 +1,152 @@
+// capi_core.hip -- handle lifecycle, device memory, workspace, timers.
+// Replaces the host new[]/memcpy/memset inside matrix<> (reference src/matrix/structure.hpp:4-26).
+#include "capi_internal.h"
+
+extern "C" {
+
+int capi_version(void) { return 100; }
+
+int capi_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+static int capi_create_common(capi_handle_t* out, int device, void* stream, bool own) {
+  if (!out) return CAPI_EINVAL;
+  capi_handle_s* h = new capi_handle_s();
+  h->device = device;
+  CAPI_HIP_CHECK(h, hipSetDevice(device));
+  if (own) {
+    CAPI_HIP_CHECK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->owns_stream = true;
+  } else {
+    h->stream = (hipStream_t)stream;
+  }
+  CAPI_HIP_CHECK(h, hipMalloc((void**)&h->d_info, sizeof(int)));
+  CAPI_HIP_CHECK(h, hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
+  CAPI_HIP_CHECK(h, hipHostMalloc((void**)&h->h_info, sizeof(int), hipHostMallocDefault));
+  CAPI_HIP_CHECK(h, hipEventCreate(&h->ev0));
+  CAPI_HIP_CHECK(h, hipEventCreate(&h->ev1));
+  hipDeviceProp_t prop;
+  CAPI_HIP_CHECK(h, hipGetDeviceProperties(&prop, device));
+  h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  *out = h;
+  return CAPI_OK;
+}
+
+int capi_create(capi_handle_t* h, int device) { return capi_create_common(h, device, nullptr, true); }
+int capi_create_on_stream(capi_handle_t* h, int device, void* s) { return capi_create_common(h, device, s, false); }
+
+int capi_destroy(capi_handle_t h) {
+  if (!h) return CAPI_EINVAL;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  if (h->ws) (void)hipFree(h->ws);
+  if (h->ws2) (void)hipFree(h->ws2);
+  if (h->d_info) (void)hipFree(h->d_info);
+  if (h->h_info) (void)hipHostFree(h->h_info);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->owns_stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return CAPI_OK;
+}
+
+void* capi_get_stream(capi_handle_t h) { return h ? (void*)h->stream : nullptr; }
+const char* capi_last_error(capi_handle_t h) { return h ? h->err : "null handle"; }
+
+int capi_malloc(capi_handle_t h, void** p, size_t bytes) {
+  CAPI_REQUIRE(h, h && p, "null");
+  hipError_t e = hipMalloc(p, bytes ? bytes : 8);
+  if (e == hipErrorOutOfMemory) { snprintf(h->err, sizeof(h->err), "hipMalloc(%zu) out of memory", bytes); return CAPI_ENOMEM; }
+  CAPI_HIP_CHECK(h, e);
+  return CAPI_OK;
+}
+int capi_free(capi_handle_t h, void* p) {
+  CAPI_REQUIRE(h, h, "null handle");
+  if (p) { CAPI_HIP_CHECK(h, hipStreamSynchronize(h->stream)); CAPI_HIP_CHECK(h, hipFree(p)); }
+  return CAPI_OK;
+}
+int capi_memset_async(capi_handle_t h, void* p, int v, size_t bytes) {
+  CAPI_REQUIRE(h, h && (p || !bytes), "null");
+  if (bytes) CAPI_HIP_CHECK(h, hipMemsetAsync(p, v, bytes, h->stream));
+  return CAPI_OK;
+}
+int capi_memcpy_h2d(capi_handle_t h, void* d, const void* s, size_t bytes) {
+  CAPI_REQUIRE(h, h, "null handle");
+  if (!bytes) return CAPI_OK;
+  CAPI_HIP_CHECK(h, hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, h->stream));
+  CAPI_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+  return CAPI_OK;
+}
+int capi_memcpy_d2h(capi_handle_t h, void* d, const void* s, size_t bytes) {
+  CAPI_REQUIRE(h, h, "null handle");
+  if (!bytes) return CAPI_OK;
+  CAPI_HIP_CHECK(h, hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToHost, h->stream));
+  CAPI_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+  return CAPI_OK;
+}
+int capi_memcpy_d2d_async(capi_handle_t h, void* d, const void* s, size_t bytes) {
+  CAPI_REQUIRE(h, h, "null handle");
+  if (bytes) CAPI_HIP_CHECK(h, hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, h->stream));
+  return CAPI_OK;
+}
+int capi_sync(capi_handle_t h) {
+  CAPI_REQUIRE(h, h, "null handle");
+  CAPI_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+  return CAPI_OK;
+}
+
+int capi_reserve_workspace(capi_handle_t h, size_t bytes) {
+  void* p;
+  return capi_ws_get(h, bytes, &p);
+}
+
+int capi_get_info(capi_handle_t h, int* info) {
+  CAPI_REQUIRE(h, h && info, "null");
+  CAPI_HIP_CHECK(h, hipMemcpyAsync(h->h_info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  CAPI_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+  *info = *h->h_info;
+  return CAPI_OK;
+}
+int capi_reset_info(capi_handle_t h) {
+  CAPI_REQUIRE(h, h, "null handle");
+  CAPI_HIP_CHECK(h, hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
+  return CAPI_OK;
+}
+
+int capi_timer_start(capi_handle_t h) {
+  CAPI_REQUIRE(h, h, "null handle");
+  CAPI_HIP_CHECK(h, hipEventRecord(h->ev0, h->stream));
+  return CAPI_OK;
+}
+int capi_timer_stop_ms(capi_handle_t h, float* ms) {
+  CAPI_REQUIRE(h, h && ms, "null");
+  CAPI_HIP_CHECK(h, hipEventRecord(h->ev1, h->stream));
+  CAPI_HIP_CHECK(h, hipEventSynchronize(h->ev1));
+  CAPI_HIP_CHECK(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+  return CAPI_OK;
+}
+
+}  // extern "C"
+
+static int ws_grow(capi_handle_t h, void** slot, size_t* cap, size_t bytes, void** p) {
+  if (!h || !p) return CAPI_EINVAL;
+  if (bytes > *cap) {
+    // stream-ordered users of the old block must finish before it is released
+    CAPI_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    if (*slot) CAPI_HIP_CHECK(h, hipFree(*slot));
+    *slot = nullptr;
+    *cap = 0;
+    size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+    hipError_t e = hipMalloc(slot, want);
+    if (e == hipErrorOutOfMemory) { snprintf(h->err, sizeof(h->err), "workspace hipMalloc(%zu) out of memory", want); return CAPI_ENOMEM; }
+    CAPI_HIP_CHECK(h, e);
+    *cap = want;
+  }
+  *p = *slot;
+  return CAPI_OK;
+}
+int capi_ws_get(capi_handle_t h, size_t bytes, void** p) { return ws_grow(h, &h->ws, &h->ws_bytes, bytes, p); }
+int capi_ws2_get(capi_handle_t h, size_t bytes, void** p) { return ws_grow(h, &h->ws2, &h->ws2_bytes, bytes, p); }

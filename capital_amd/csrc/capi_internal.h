@@ -1,0 +1,48 @@
+// capi_internal.h -- private state of libcapital_hip.so (gfx950 only; no CUDA/compat paths).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "capital_hip.h"
+
+struct capi_handle_s {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool owns_stream = false;
+  // private workspace (in-place trmm staging, split-K slabs, potrf panels); grows on demand
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+  // second, independent scratch block (diagonal-block inverses, recursion temporaries)
+  void* ws2 = nullptr;
+  size_t ws2_bytes = 0;
+  // device-side LAPACK info word (0 ok, >0 first bad pivot, 1-based) + pinned host mirror
+  int* d_info = nullptr;
+  int* h_info = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int num_cu = 256;
+  char err[512] = {0};
+};
+
+#define CAPI_HIP_CHECK(h, call)                                                              \
+  do {                                                                                       \
+    hipError_t e__ = (call);                                                                 \
+    if (e__ != hipSuccess) {                                                                 \
+      if (h) snprintf((h)->err, sizeof((h)->err), "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e__)); \
+      return CAPI_EHIP;                                                                      \
+    }                                                                                        \
+  } while (0)
+
+#define CAPI_REQUIRE(h, cond, msg)                                                           \
+  do {                                                                                       \
+    if (!(cond)) {                                                                           \
+      if (h) snprintf((h)->err, sizeof((h)->err), "%s:%d invalid argument: %s", __FILE__, __LINE__, msg); \
+      return CAPI_EINVAL;                                                                    \
+    }                                                                                        \
+  } while (0)
+
+// returns a workspace pointer of at least `bytes` (stream-ordered reuse: callers run on h->stream)
+int capi_ws_get(capi_handle_t h, size_t bytes, void** p);
+int capi_ws2_get(capi_handle_t h, size_t bytes, void** p);
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1,0 +1,192 @@
+// comm_rccl.hip -- the reference's MPI collectives (C1-C10) as RCCL calls on the handle's HIP
+// stream.  RCCL is bound at run time with dlopen so that (a) single-GPU use never loads it and (b) inside a
+// torch.distributed process the SAME librccl.so.1 that torch already mapped is reused (one RCCL per process).
+// One process per GPU; communicators of size 1 short-circuit every call.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include "capi_internal.h"
+
+struct capi_comm_s {
+  ncclComm_t comm = nullptr;
+  capi_handle_t h = nullptr;
+  int rank = 0, size = 1;
+};
+
+namespace {
+
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommSplit)(ncclComm_t, int, int, ncclComm_t*, ncclConfig_t*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+} g_rccl;
+
+char g_rccl_err[256] = {0};
+
+int rccl_bind(const char* path) {
+  if (g_rccl.lib) return CAPI_OK;
+  const char* candidates[] = {path, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", nullptr};
+  void* lib = nullptr;
+  for (int i = 0; i < 5 && !lib; ++i) {
+    if (!candidates[i]) { if (i == 0) continue; else break; }
+    // prefer a copy that is already mapped into this process (torch's), then load by name
+    lib = dlopen(candidates[i], RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+    if (!lib) lib = dlopen(candidates[i], RTLD_NOW | RTLD_GLOBAL);
+  }
+  if (!lib) { snprintf(g_rccl_err, sizeof(g_rccl_err), "cannot load librccl: %s", dlerror()); return CAPI_ECOMM; }
+#define BIND(field, sym)                                                                       \
+  *(void**)(&g_rccl.field) = dlsym(lib, sym);                                                  \
+  if (!g_rccl.field) { snprintf(g_rccl_err, sizeof(g_rccl_err), "librccl lacks %s", sym); return CAPI_ECOMM; }
+  BIND(GetUniqueId, "ncclGetUniqueId")
+  BIND(CommInitRank, "ncclCommInitRank")
+  BIND(CommSplit, "ncclCommSplit")
+  BIND(CommDestroy, "ncclCommDestroy")
+  BIND(Broadcast, "ncclBroadcast")
+  BIND(AllReduce, "ncclAllReduce")
+  BIND(Reduce, "ncclReduce")
+  BIND(AllGather, "ncclAllGather")
+  BIND(Send, "ncclSend")
+  BIND(Recv, "ncclRecv")
+  BIND(GroupStart, "ncclGroupStart")
+  BIND(GroupEnd, "ncclGroupEnd")
+  BIND(GetErrorString, "ncclGetErrorString")
+#undef BIND
+  g_rccl.lib = lib;
+  return CAPI_OK;
+}
+
+#define NCCL_CHECK(c, call)                                                                      \
+  do {                                                                                           \
+    ncclResult_t r__ = (call);                                                                   \
+    if (r__ != ncclSuccess) {                                                                    \
+      if ((c) && (c)->h) snprintf((c)->h->err, sizeof((c)->h->err), "%s:%d %s -> %s", __FILE__, __LINE__, #call, g_rccl.GetErrorString(r__)); \
+      return CAPI_ECOMM;                                                                         \
+    }                                                                                            \
+  } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int capi_comm_load_rccl(const char* path) { return rccl_bind(path); }
+
+int capi_comm_unique_id(void* id128) {
+  if (!id128) return CAPI_EINVAL;
+  int rc = rccl_bind(nullptr);
+  if (rc != CAPI_OK) return rc;
+  static_assert(sizeof(ncclUniqueId) == 128, "RCCL unique id is 128 bytes");
+  ncclUniqueId id;
+  if (g_rccl.GetUniqueId(&id) != ncclSuccess) return CAPI_ECOMM;
+  memcpy(id128, &id, sizeof(id));
+  return CAPI_OK;
+}
+
+int capi_comm_init_rank(capi_comm_t* out, capi_handle_t h, int nranks, const void* id128, int rank) {
+  CAPI_REQUIRE(h, h && out && nranks >= 1 && rank >= 0 && rank < nranks, "args");
+  capi_comm_s* c = new capi_comm_s();
+  c->h = h;
+  c->rank = rank;
+  c->size = nranks;
+  if (nranks > 1) {
+    CAPI_REQUIRE(h, id128, "unique id");
+    int rc = rccl_bind(nullptr);
+    if (rc != CAPI_OK) { snprintf(h->err, sizeof(h->err), "%s", g_rccl_err); delete c; return rc; }
+    CAPI_HIP_CHECK(h, hipSetDevice(h->device));
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    NCCL_CHECK(c, g_rccl.CommInitRank(&c->comm, nranks, id, rank));
+  }
+  *out = c;
+  return CAPI_OK;
+}
+
+int capi_comm_split(capi_comm_t parent, int color, int key, capi_comm_t* child) {
+  if (!parent || !child) return CAPI_EINVAL;
+  capi_comm_s* c = new capi_comm_s();
+  c->h = parent->h;
+  if (parent->size == 1) {
+    c->rank = 0;
+    c->size = 1;
+  } else {
+    NCCL_CHECK(parent, g_rccl.CommSplit(parent->comm, color, key, &c->comm, nullptr));
+    // rank/size of the child: RCCL orders by key then parent rank; recover them from the library
+    int (*cu)(const ncclComm_t, int*) = (int (*)(const ncclComm_t, int*))dlsym(g_rccl.lib, "ncclCommUserRank");
+    int (*cc)(const ncclComm_t, int*) = (int (*)(const ncclComm_t, int*))dlsym(g_rccl.lib, "ncclCommCount");
+    if (!cu || !cc || cu(c->comm, &c->rank) != 0 || cc(c->comm, &c->size) != 0) return CAPI_ECOMM;
+  }
+  *child = c;
+  return CAPI_OK;
+}
+
+int capi_comm_rank(capi_comm_t c, int* rank) { if (!c || !rank) return CAPI_EINVAL; *rank = c->rank; return CAPI_OK; }
+int capi_comm_size(capi_comm_t c, int* size) { if (!c || !size) return CAPI_EINVAL; *size = c->size; return CAPI_OK; }
+
+int capi_comm_destroy(capi_comm_t c) {
+  if (!c) return CAPI_EINVAL;
+  if (c->comm) {
+    (void)hipStreamSynchronize(c->h->stream);
+    g_rccl.CommDestroy(c->comm);
+  }
+  delete c;
+  return CAPI_OK;
+}
+
+int capi_bcast(capi_comm_t c, double* buf, int64_t count, int root) {
+  if (!c || count < 0 || root < 0 || root >= c->size) return CAPI_EINVAL;
+  if (c->size == 1 || count == 0) return CAPI_OK;
+  NCCL_CHECK(c, g_rccl.Broadcast(buf, buf, (size_t)count, ncclDouble, root, c->comm, c->h->stream));
+  return CAPI_OK;
+}
+
+int capi_allreduce_sum(capi_comm_t c, double* buf, int64_t count) {
+  if (!c || count < 0) return CAPI_EINVAL;
+  if (c->size == 1 || count == 0) return CAPI_OK;
+  NCCL_CHECK(c, g_rccl.AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, c->comm, c->h->stream));
+  return CAPI_OK;
+}
+
+int capi_reduce_sum(capi_comm_t c, const double* send, double* recv, int64_t count, int root) {
+  if (!c || count < 0 || root < 0 || root >= c->size) return CAPI_EINVAL;
+  if (count == 0) return CAPI_OK;
+  if (c->size == 1) {
+    if (send != recv) CAPI_HIP_CHECK(c->h, hipMemcpyAsync(recv, send, sizeof(double) * count, hipMemcpyDeviceToDevice, c->h->stream));
+    return CAPI_OK;
+  }
+  NCCL_CHECK(c, g_rccl.Reduce(send, recv, (size_t)count, ncclDouble, ncclSum, root, c->comm, c->h->stream));
+  return CAPI_OK;
+}
+
+int capi_allgather(capi_comm_t c, const double* send, double* recv, int64_t count) {
+  if (!c || count < 0) return CAPI_EINVAL;
+  if (count == 0) return CAPI_OK;
+  if (c->size == 1) {
+    if (send != recv) CAPI_HIP_CHECK(c->h, hipMemcpyAsync(recv, send, sizeof(double) * count, hipMemcpyDeviceToDevice, c->h->stream));
+    return CAPI_OK;
+  }
+  NCCL_CHECK(c, g_rccl.AllGather(send, recv, (size_t)count, ncclDouble, c->comm, c->h->stream));
+  return CAPI_OK;
+}
+
+int capi_sendrecv_replace(capi_comm_t c, double* buf, int64_t count, int peer, double* staging) {
+  if (!c || count < 0 || peer < 0 || peer >= c->size) return CAPI_EINVAL;
+  if (count == 0 || peer == c->rank) return CAPI_OK;
+  if (!staging) return CAPI_EINVAL;
+  NCCL_CHECK(c, g_rccl.GroupStart());
+  NCCL_CHECK(c, g_rccl.Send(buf, (size_t)count, ncclDouble, peer, c->comm, c->h->stream));
+  NCCL_CHECK(c, g_rccl.Recv(staging, (size_t)count, ncclDouble, peer, c->comm, c->h->stream));
+  NCCL_CHECK(c, g_rccl.GroupEnd());
+  CAPI_HIP_CHECK(c->h, hipMemcpyAsync(buf, staging, sizeof(double) * count, hipMemcpyDeviceToDevice, c->h->stream));
+  return CAPI_OK;
+}
+
+}  // extern "C"

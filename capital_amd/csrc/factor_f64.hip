@@ -1,0 +1,338 @@
+// factor_f64.hip -- panel POTRF / TRTRI / TRSM for gfx950.
+//
+// Replaces LAPACKE_dpotrf / LAPACKE_dtrtri behind the reference's lapack::engine
+// (src/lapack/interface.hpp:30-58) and adds the block TRSM the reference lacks.
+//
+// Structure: one LDS-resident leaf kernel factors AND inverts a diagonal block of order <= 64 in a single
+// launch (the reference's base case is exactly this pair: potrf, memcpy, trtri -- cholinv/policy.h:199-201,
+// cacqr.hpp:20-22); everything larger is the same recursion the reference runs across MPI ranks
+// (cholinv.hpp:87-165), executed here on one device with the MFMA tile kernel of gemm_f64.hip:
+//   R11,X11 = leaf/rec(A11);  R12 = X11^T A12;  A22 -= R12^T R12;  R22,X22 = rec(A22);  X12 = -X11 R12 X22.
+#include "capi_internal.h"
+
+int capi_ws2_get(capi_handle_t h, size_t bytes, void** p);
+
+namespace {
+
+constexpr int LEAF = 64;
+constexpr int LDL = LEAF + 1;  // odd leading dimension: conflict-free ds_read_b64 along a row
+
+// One workgroup.  A: b x b upper triangle in (lda); on exit A(upper) = R with A = R^T R, X(upper) = R^-1.
+// want_inv == 0 skips the inverse.  zero_lower: also write zeros below the diagonal of both outputs.
+// invert_only: A already holds a triangular R (skip the Cholesky sweep); unit: unit diagonal (invert_only)
+__global__ __launch_bounds__(256) void potrf_trtri_leaf_kernel(double* __restrict__ A, int64_t lda, double* __restrict__ X,
+                                                               int64_t ldx, int b, int want_inv, int zero_lower,
+                                                               int invert_only, int unit, int* __restrict__ info,
+                                                               int info_base) {
+  __shared__ double R[LEAF * LDL];
+  __shared__ double S[LEAF * LDL];
+  __shared__ double piv[LEAF];
+  const int tid = threadIdx.x;
+  const int c = tid & 63, rg = tid >> 6;
+
+  // load upper triangle (coalesced along rows of a column)
+  for (int col = rg; col < b; col += 4) {
+    const int row = c;
+    if (row < b) {
+      double v = (row <= col) ? A[row + (int64_t)col * lda] : 0.0;
+      if (unit && row == col) v = 1.0;
+      R[row + col * LDL] = v;
+      S[row + col * LDL] = 0.0;
+    }
+  }
+  __syncthreads();
+
+  if (!invert_only) {
+    // right-looking Cholesky with ONE barrier per step.  Step j: (a) trailing update with the UNSCALED row j,
+    // R[r,c] -= R[j,r]*R[j,c]/p_j (j<r<=c); (b) scale the finished row j-1 by 1/sqrt(p_{j-1}).  Rows touched by
+    // (a) and (b) are disjoint.  Pivots are parked in piv[] and the diagonal is written once at the end.
+    for (int j = 0; j < b; ++j) {
+      double p = R[j + j * LDL];
+      if (!(p > 0.0)) {
+        if (tid == 0) atomicCAS(info, 0, info_base + j + 1);
+        p = 1.0;
+      }
+      if (tid == 0) piv[j] = p;
+      const double ip = 1.0 / p;
+      if (c > j && c < b) {
+        const double rjc = R[j + c * LDL] * ip;
+        for (int r = j + 1 + rg; r <= c; r += 4) R[r + c * LDL] -= R[j + r * LDL] * rjc;
+      }
+      if (j > 0 && rg == 3 && c > j - 1 && c < b) R[(j - 1) + c * LDL] *= 1.0 / sqrt(piv[j - 1]);
+      __syncthreads();
+    }
+    if (rg == 0 && c < b) R[c + c * LDL] = sqrt(piv[c]);
+    __syncthreads();
+  }
+
+  if (want_inv) {
+    // X = R^-1 by rows from the bottom: X[p,c] = (delta_pc - S[p,c]) / R[p,p], S[j,c] += R[j,p]*X[p,c] (j<p).
+    // One barrier per step: step p reads row p of S (complete), updates rows j<p; row p is finalised in place
+    // during step p-1 (nobody reads it then).
+    for (int p = b - 1; p >= 0; --p) {
+      const double ipp = 1.0 / R[p + p * LDL];
+      if (c >= p && c < b) {
+        const double xpc = ((c == p ? 1.0 : 0.0) - S[p + c * LDL]) * ipp;
+        for (int j = rg; j < p; j += 4) S[j + c * LDL] += R[j + p * LDL] * xpc;
+      }
+      if (p + 1 < b && rg == 0 && c >= p + 1 && c < b) {
+        const double iqq = 1.0 / R[(p + 1) + (p + 1) * LDL];
+        S[(p + 1) + c * LDL] = ((c == p + 1 ? 1.0 : 0.0) - S[(p + 1) + c * LDL]) * iqq;
+      }
+      __syncthreads();
+    }
+    if (b > 0 && rg == 0 && c < b) {
+      const double i00 = 1.0 / R[0];
+      S[0 + c * LDL] = ((c == 0 ? 1.0 : 0.0) - S[0 + c * LDL]) * i00;
+    }
+    __syncthreads();
+  }
+
+  for (int col = rg; col < b; col += 4) {
+    const int row = c;
+    if (row < b) {
+      if (row <= col) {
+        if (!invert_only) A[row + (int64_t)col * lda] = R[row + col * LDL];
+        if (want_inv) X[row + (int64_t)col * ldx] = S[row + col * LDL];
+      } else if (zero_lower) {
+        if (!invert_only) A[row + (int64_t)col * lda] = 0.0;
+        if (want_inv) X[row + (int64_t)col * ldx] = 0.0;
+      }
+    }
+  }
+}
+
+__global__ void scale2d_kernel(double* __restrict__ B, int64_t ldb, int64_t m, int64_t n, double alpha) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  for (int64_t j = blockIdx.y; j < n; j += gridDim.y) B[i + j * ldb] = alpha == 0.0 ? 0.0 : alpha * B[i + j * ldb];
+}
+
+int64_t split_point(int64_t n) {
+  int64_t h = ((n / 2 + LEAF - 1) / LEAF) * LEAF;
+  if (h >= n) h = (n / 2) & ~(int64_t)1;
+  if (h <= 0) h = n / 2;
+  return h;
+}
+
+int leaf_launch(capi_handle_t h, double* A, int64_t lda, double* X, int64_t ldx, int b, int want_inv, int zero_lower,
+                int invert_only, int unit, int info_base) {
+  hipLaunchKernelGGL(potrf_trtri_leaf_kernel, dim3(1), dim3(256), 0, h->stream, A, lda, X, ldx, b, want_inv, zero_lower,
+                     invert_only, unit, h->d_info, info_base);
+  CAPI_HIP_CHECK(h, hipGetLastError());
+  return CAPI_OK;
+}
+
+#define RC(x) do { int rc__ = (x); if (rc__ != CAPI_OK) return rc__; } while (0)
+
+// cholinv on one device: A(upper) -> R, X <- R^-1 (upper).  W: n/2 x n/2-ish scratch (ld = ldw) for R12 products.
+int potrf_trtri_rec(capi_handle_t h, int64_t n, double* A, int64_t lda, double* X, int64_t ldx, int zero_lower, int info_base) {
+  if (n <= LEAF) return leaf_launch(h, A, lda, X, ldx, (int)n, 1, zero_lower, 0, 0, info_base);
+  const int64_t n1 = split_point(n), n2 = n - n1;
+  double* A12 = A + n1 * lda;
+  double* A22 = A + n1 + n1 * lda;
+  double* X12 = X + n1 * ldx;
+  double* X22 = X + n1 + n1 * ldx;
+  RC(potrf_trtri_rec(h, n1, A, lda, X, ldx, zero_lower, info_base));
+  // R12 = X11^T A12 : staged through X12's storage (free until step 5), then copied into place
+  RC(capi_dtrmm_oop(h, CAPI_LEFT, CAPI_UPPER, CAPI_TRANS, CAPI_NONUNIT, n1, n2, 1.0, X, ldx, A12, lda, X12, ldx));
+  RC(capi_dlacpy(h, 0, n1, n2, X12, ldx, A12, lda));
+  RC(capi_dgemmt(h, CAPI_UPPER, CAPI_TRANS, CAPI_NOTRANS, n2, n1, -1.0, A12, lda, A12, lda, 1.0, A22, lda));
+  RC(potrf_trtri_rec(h, n2, A22, lda, X22, ldx, zero_lower, info_base + (int)n1));
+  // X12 = -X11 * R12 * X22 : T = X11*R12 into the strictly-lower-free scratch below, then X12 = -T*X22
+  void* w;
+  RC(capi_ws2_get(h, sizeof(double) * (size_t)n1 * (size_t)n2, &w));
+  RC(capi_dtrmm_oop(h, CAPI_LEFT, CAPI_UPPER, CAPI_NOTRANS, CAPI_NONUNIT, n1, n2, 1.0, X, ldx, A12, lda, (double*)w, n1));
+  RC(capi_dtrmm_oop(h, CAPI_RIGHT, CAPI_UPPER, CAPI_NOTRANS, CAPI_NONUNIT, n1, n2, -1.0, X22, ldx, (double*)w, n1, X12, ldx));
+  if (zero_lower) {
+    // lower-left n2 x n1 blocks of both outputs
+    hipStream_t s = h->stream;
+    CAPI_HIP_CHECK(h, hipMemset2DAsync(A + n1, sizeof(double) * lda, 0, sizeof(double) * n2, n1, s));
+    CAPI_HIP_CHECK(h, hipMemset2DAsync(X + n1, sizeof(double) * ldx, 0, sizeof(double) * n2, n1, s));
+  }
+  return CAPI_OK;
+}
+
+// in-place inverse of an upper triangular matrix (non-unit or unit diagonal)
+int trtri_upper_rec(capi_handle_t h, int diag, int64_t n, double* T, int64_t ldt) {
+  if (n <= LEAF) return leaf_launch(h, T, ldt, T, ldt, (int)n, 1, 0, 1, diag == CAPI_UNIT, 0);
+  const int64_t n1 = split_point(n), n2 = n - n1;
+  double* T12 = T + n1 * ldt;
+  double* T22 = T + n1 + n1 * ldt;
+  RC(trtri_upper_rec(h, diag, n1, T, ldt));
+  RC(trtri_upper_rec(h, diag, n2, T22, ldt));
+  void* w;
+  RC(capi_ws2_get(h, sizeof(double) * (size_t)n1 * (size_t)n2, &w));
+  RC(capi_dtrmm_oop(h, CAPI_LEFT, CAPI_UPPER, CAPI_NOTRANS, CAPI_NONUNIT, n1, n2, 1.0, T, ldt, T12, ldt, (double*)w, n1));
+  RC(capi_dtrmm_oop(h, CAPI_RIGHT, CAPI_UPPER, CAPI_NOTRANS, CAPI_NONUNIT, n1, n2, -1.0, T22, ldt, (double*)w, n1, T12, ldt));
+  return CAPI_OK;
+}
+
+__global__ void transpose_tri_kernel(const double* __restrict__ src, int64_t lds_, double* __restrict__ dst, int64_t ldd, int64_t n,
+                                     int src_upper) {
+  // dst (full n x n scratch) upper <- src lower^T  (src_upper == 0), or dst lower <- src upper^T
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int64_t j = blockIdx.y; j < n; j += gridDim.y) {
+    const bool in_src = src_upper ? (i <= j) : (i >= j);
+    if (in_src) dst[j + i * ldd] = src[i + j * lds_];
+  }
+}
+
+const int TRSM_LEAF = 256;
+
+// E = op(T).  Left: E X = B;  Right: X E = B.  In place on B.
+int trsm_rec(capi_handle_t h, int side, int uplo, int trans, int diag, int64_t m, int64_t n, const double* T, int64_t ldt,
+             double* B, int64_t ldb) {
+  const int64_t nt = side == CAPI_LEFT ? m : n;
+  const bool eff_upper = (uplo == CAPI_UPPER) != (trans == CAPI_TRANS);
+  if (nt <= TRSM_LEAF) {
+    // invert the diagonal block into scratch, then multiply
+    void* w;
+    RC(capi_ws2_get(h, sizeof(double) * (size_t)TRSM_LEAF * TRSM_LEAF * 2, &w));
+    double* Ti = (double*)w + (size_t)TRSM_LEAF * TRSM_LEAF;  // first half: the inverse recursion's temporaries
+    if (uplo == CAPI_UPPER) {
+      RC(capi_dlacpy(h, 1, nt, nt, T, ldt, Ti, nt));
+      RC(trtri_upper_rec(h, diag, nt, Ti, nt));
+      return capi_dtrmm(h, side, CAPI_UPPER, trans, diag, m, n, 1.0, Ti, nt, B, ldb);
+    } else {
+      // lower: invert its transpose (upper), use with the opposite transpose flag
+      dim3 grid((unsigned)cdiv(nt, 256), (unsigned)(nt < 65535 ? nt : 65535));
+      hipLaunchKernelGGL(transpose_tri_kernel, grid, dim3(256), 0, h->stream, T, ldt, Ti, nt, nt, 0);
+      CAPI_HIP_CHECK(h, hipGetLastError());
+      RC(trtri_upper_rec(h, diag, nt, Ti, nt));
+      return capi_dtrmm(h, side, CAPI_UPPER, trans == CAPI_TRANS ? CAPI_NOTRANS : CAPI_TRANS, diag, m, n, 1.0, Ti, nt, B, ldb);
+    }
+  }
+  const int64_t n1 = split_point(nt), n2 = nt - n1;
+  const double* T11 = T;
+  const double* T22 = T + n1 + n1 * ldt;
+  // off-diagonal block of E between index ranges 1 and 2
+  const double* Toff = (uplo == CAPI_UPPER) ? T + n1 * ldt /* T12: n1 x n2 */ : T + n1 /* T21: n2 x n1 */;
+  if (side == CAPI_LEFT) {
+    double* B1 = B;
+    double* B2 = B + n1;
+    if (eff_upper) {
+      // E12 = trans ? T21^T : T12
+      RC(trsm_rec(h, side, uplo, trans, diag, n2, n, T22, ldt, B2, ldb));
+      RC(capi_dgemm(h, trans, CAPI_NOTRANS, n1, n, n2, -1.0, Toff, ldt, B2, ldb, 1.0, B1, ldb));
+      RC(trsm_rec(h, side, uplo, trans, diag, n1, n, T11, ldt, B1, ldb));
+    } else {
+      // E21 = trans ? T12^T : T21
+      RC(trsm_rec(h, side, uplo, trans, diag, n1, n, T11, ldt, B1, ldb));
+      RC(capi_dgemm(h, trans, CAPI_NOTRANS, n2, n, n1, -1.0, Toff, ldt, B1, ldb, 1.0, B2, ldb));
+      RC(trsm_rec(h, side, uplo, trans, diag, n2, n, T22, ldt, B2, ldb));
+    }
+  } else {
+    double* B1 = B;
+    double* B2 = B + n1 * ldb;
+    if (eff_upper) {
+      RC(trsm_rec(h, side, uplo, trans, diag, m, n1, T11, ldt, B1, ldb));
+      RC(capi_dgemm(h, CAPI_NOTRANS, trans, m, n2, n1, -1.0, B1, ldb, Toff, ldt, 1.0, B2, ldb));
+      RC(trsm_rec(h, side, uplo, trans, diag, m, n2, T22, ldt, B2, ldb));
+    } else {
+      RC(trsm_rec(h, side, uplo, trans, diag, m, n2, T22, ldt, B2, ldb));
+      RC(capi_dgemm(h, CAPI_NOTRANS, trans, m, n1, n2, -1.0, B2, ldb, Toff, ldt, 1.0, B1, ldb));
+      RC(trsm_rec(h, side, uplo, trans, diag, m, n1, T11, ldt, B1, ldb));
+    }
+  }
+  return CAPI_OK;
+}
+
+bool ok01(int v) { return v == 0 || v == 1; }
+
+}  // namespace
+
+extern "C" {
+
+int capi_dpotrf_trtri(capi_handle_t h, int64_t n, double* A, int64_t lda, double* Rinv, int64_t ldi) {
+  CAPI_REQUIRE(h, h, "null handle");
+  CAPI_REQUIRE(h, n >= 0 && n < (1LL << 31), "n");
+  if (n == 0) return CAPI_OK;
+  CAPI_REQUIRE(h, A && Rinv && lda >= n && ldi >= n, "operands");
+  { void* w; RC(capi_ws2_get(h, sizeof(double) * (size_t)(n / 2 + LEAF) * (size_t)(n / 2 + LEAF), &w)); }
+  return potrf_trtri_rec(h, n, A, lda, Rinv, ldi, 1, 0);
+}
+
+int capi_dpotrf(capi_handle_t h, int uplo, int64_t n, double* A, int64_t lda) {
+  CAPI_REQUIRE(h, h, "null handle");
+  CAPI_REQUIRE(h, ok01(uplo), "uplo code");
+  CAPI_REQUIRE(h, n >= 0 && n < (1LL << 31), "n");
+  if (n == 0) return CAPI_OK;
+  CAPI_REQUIRE(h, A && lda >= n, "A/lda");
+  // cholinv.hpp:9 -- the hot path only ever factors 'U'.  'L' is served by factoring the transpose.
+  if (uplo == CAPI_LOWER) {
+    void* w;
+    RC(capi_ws2_get(h, sizeof(double) * (size_t)n * (size_t)n * 3, &w));
+    double* U = (double*)w + (size_t)n * n * 2;  // the upper-case call below uses at most the first 2*n*n
+    dim3 grid((unsigned)cdiv(n, 256), (unsigned)(n < 65535 ? n : 65535));
+    hipLaunchKernelGGL(transpose_tri_kernel, grid, dim3(256), 0, h->stream, A, lda, U, n, n, 0);
+    CAPI_HIP_CHECK(h, hipGetLastError());
+    RC(capi_dpotrf(h, CAPI_UPPER, n, U, n));
+    hipLaunchKernelGGL(transpose_tri_kernel, grid, dim3(256), 0, h->stream, U, n, A, lda, n, 1);
+    CAPI_HIP_CHECK(h, hipGetLastError());
+    return CAPI_OK;
+  }
+  // blocked right-looking with diagonal blocks of order NB factored-and-inverted by the recursion above
+  const int64_t NB = 1024;
+  if (n <= LEAF) return leaf_launch(h, A, lda, A, lda, (int)n, 0, 0, 0, 0, 0);
+  const int64_t nb0 = n < NB ? n : NB;
+  double* Xd = nullptr;
+  {
+    // diag inverse lives in its own allocation slice: first nb0*nb0 doubles of scratch-2 are used by the
+    // recursion's temporaries only up to (nb0/2)^2, so place Xd after them.
+    void* w2;
+    RC(capi_ws2_get(h, sizeof(double) * (size_t)nb0 * nb0 * 2, &w2));
+    Xd = (double*)w2 + (size_t)nb0 * nb0;
+  }
+  for (int64_t j0 = 0; j0 < n; j0 += NB) {
+    const int64_t jb = (n - j0) < NB ? (n - j0) : NB, rest = n - j0 - jb;
+    double* Ajj = A + j0 + j0 * lda;
+    RC(potrf_trtri_rec(h, jb, Ajj, lda, Xd, nb0, 0, (int)j0));
+    if (rest > 0) {
+      double* A12 = A + j0 + (j0 + jb) * lda;
+      RC(capi_dtrmm(h, CAPI_LEFT, CAPI_UPPER, CAPI_TRANS, CAPI_NONUNIT, jb, rest, 1.0, Xd, nb0, A12, lda));
+      RC(capi_dgemmt(h, CAPI_UPPER, CAPI_TRANS, CAPI_NOTRANS, rest, jb, -1.0, A12, lda, A12, lda, 1.0,
+                     A + (j0 + jb) + (j0 + jb) * lda, lda));
+    }
+  }
+  return CAPI_OK;
+}
+
+int capi_dtrtri(capi_handle_t h, int uplo, int diag, int64_t n, double* A, int64_t lda) {
+  CAPI_REQUIRE(h, h, "null handle");
+  CAPI_REQUIRE(h, ok01(uplo) && ok01(diag), "enum code");
+  CAPI_REQUIRE(h, n >= 0 && n < (1LL << 31), "n");
+  if (n == 0) return CAPI_OK;
+  CAPI_REQUIRE(h, A && lda >= n, "A/lda");
+  if (uplo == CAPI_UPPER) return trtri_upper_rec(h, diag, n, A, lda);
+  void* w;
+  RC(capi_ws2_get(h, sizeof(double) * (size_t)n * (size_t)n * 2, &w));
+  double* U = (double*)w + (size_t)n * n;
+  dim3 grid((unsigned)cdiv(n, 256), (unsigned)(n < 65535 ? n : 65535));
+  hipLaunchKernelGGL(transpose_tri_kernel, grid, dim3(256), 0, h->stream, A, lda, U, n, n, 0);
+  CAPI_HIP_CHECK(h, hipGetLastError());
+  RC(trtri_upper_rec(h, diag, n, U, n));
+  hipLaunchKernelGGL(transpose_tri_kernel, grid, dim3(256), 0, h->stream, U, n, A, lda, n, 1);
+  CAPI_HIP_CHECK(h, hipGetLastError());
+  return CAPI_OK;
+}
+
+int capi_dtrsm(capi_handle_t h, int side, int uplo, int trans, int diag, int64_t m, int64_t n, double alpha,
+               const double* T, int64_t ldt, double* B, int64_t ldb) {
+  CAPI_REQUIRE(h, h, "null handle");
+  CAPI_REQUIRE(h, ok01(side) && ok01(uplo) && ok01(trans) && ok01(diag), "enum code");
+  CAPI_REQUIRE(h, m >= 0 && n >= 0 && m < (1LL << 31) && n < (1LL << 31), "dims");
+  if (m == 0 || n == 0) return CAPI_OK;
+  const int64_t nt = side == CAPI_LEFT ? m : n;
+  CAPI_REQUIRE(h, T && B && ldt >= nt && ldb >= m, "operands");
+  if (alpha != 1.0) {
+    dim3 grid((unsigned)cdiv(m, 256), (unsigned)(n < 65535 ? n : 65535));
+    hipLaunchKernelGGL(scale2d_kernel, grid, dim3(256), 0, h->stream, B, ldb, m, n, alpha);
+    CAPI_HIP_CHECK(h, hipGetLastError());
+    if (alpha == 0.0) return CAPI_OK;
+  }
+  return trsm_rec(h, side, uplo, trans, diag, m, n, T, ldt, B, ldb);
+}
+
+}  // extern "C"

@@ -1,0 +1,494 @@
+// gemm_f64.hip -- fp64 MFMA (v_mfma_f64_16x16x4_f64) tile kernel for gfx950 and the BLAS-level
+// C-ABI entry points built on it: capi_dgemm / capi_dgemmt / capi_dsyrk / capi_dtrmm[_oop].
+//
+// Replaces cblas_dgemm / cblas_dsyrk / cblas_dtrmm behind the reference's blas::engine
+// (src/blas/interface.hpp:43-97).  One templated kernel serves all of them:
+//   * 128x128 output tile per 256-thread workgroup (4 waves = one per SIMD, 2 workgroups per CU),
+//     each wave owns a 64x64 block = 4x4 MFMA tiles of 16x16 (64 fp64 accumulators per lane);
+//   * K is consumed in 16-deep panels, double-buffered in LDS (one barrier per panel), staged
+//     global -> registers (16-byte coalesced loads) -> LDS while the MFMAs of the current panel run;
+//   * an operand panel is kept in LDS in the orientation it has in HBM (k-contiguous [row][k] with
+//     a 2-double pad, or row-contiguous [k][row] with an 8-double pad) so that staging is a pure
+//     16-byte copy and fragment reads are bank-conflict free or at worst 2-way;
+//   * the MFMA's A operand is fed from the N-side panel and its B operand from the M-side panel, so the
+//     accumulator's lane index runs along C's column-major rows and the epilogue stores 128-byte runs;
+//   * triangular work is skipped at tile granularity: GEMMT/SYRK launch only the tiles of the wanted
+//     triangle, TRMM shortens each tile's k-range to the non-zero band and masks the diagonal panels;
+//   * split-K (tall-skinny Gram matrices of CholeskyQR2) writes per-slice partial tiles to a slab that a
+//     second kernel reduces in a fixed order (bit-reproducible, no atomics);
+//   * workgroup ids are re-dealt so that the 64 tiles an XCD runs concurrently form a compact block
+//     of the output (8 XCDs x private 4 MiB L2).
+#include "capi_internal.h"
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16, NTHREADS = 256;
+constexpr int SK = BK + 2;            // [row][k] layout: row stride in doubles (144 B, 16-B aligned, odd multiple of 16 B)
+constexpr int SR = 128 + 8;           // [k][row] layout: k-row stride in doubles (1088 B)
+constexpr int TILE_LDS = 128 * SK;    // 2304 doubles >= BK*SR = 2176
+constexpr int STAGE_LDS = 2 * TILE_LDS;
+constexpr int GROUP_M = 8;
+
+struct GemmArgs {
+  const double* A;
+  const double* B;
+  double* C;
+  int64_t lda, ldb, ldc;
+  int M, N, K;
+  double alpha, beta;
+  int out_uplo;       // -1: full output; CAPI_UPPER / CAPI_LOWER: only that triangle of C (M == N)
+  int tri_side;       // -1: none; CAPI_LEFT: op(A) is triangular (M == K); CAPI_RIGHT: op(B) is triangular (N == K)
+  int tri_eff_upper;  // op(T) is upper triangular
+  int tri_unit;
+  int a_vec, b_vec;   // 16-byte loads legal for A / B
+  int splitk, k_per_split;
+  double* slab;       // split-K partial sums: slab[z*slab_stride + i + j*slab_ld]
+  int64_t slab_ld, slab_stride;
+  int tiles_m, tiles_n, ntiles;
+};
+
+// ---- global -> registers: this thread's 4 x 16 bytes of a 128 x 16 operand panel -----------------
+template <bool KC>
+__device__ __forceinline__ void panel_load(const double* __restrict__ X, int64_t ld, int r0, int R, int k0, int kend,
+                                           int tid, bool vec_ok, d2_t (&v)[4]) {
+  if (KC) {  // element (r,k) at X[k + r*ld]
+    const int kp = tid & 7, rb = tid >> 3;
+    const int k = k0 + 2 * kp;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = r0 + rb + 32 * q;
+      d2_t val = {0.0, 0.0};
+      if (r < R) {
+        const double* p = X + (int64_t)r * ld + k;
+        if (vec_ok && k + 1 < kend) {
+          val = *(const d2_t*)p;
+        } else {
+          if (k < kend) val.x = p[0];
+          if (k + 1 < kend) val.y = p[1];
+        }
+      }
+      v[q] = val;
+    }
+  } else {  // element (r,k) at X[r + k*ld]
+    const int rp = tid & 63, kb = tid >> 6;
+    const int r = r0 + 2 * rp;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = k0 + kb + 4 * q;
+      d2_t val = {0.0, 0.0};
+      if (k < kend) {
+        const double* p = X + (int64_t)k * ld + r;
+        if (vec_ok && r + 1 < R) {
+          val = *(const d2_t*)p;
+        } else {
+          if (r < R) val.x = p[0];
+          if (r + 1 < R) val.y = p[1];
+        }
+      }
+      v[q] = val;
+    }
+  }
+}
+
+// zero what lies outside the triangle of op(T) (and force a unit diagonal) on a staged panel.
+// keep_ge: keep k >= r, else keep k <= r  (r = the panel's row index in op(T) coordinates)
+template <bool KC>
+__device__ __forceinline__ void panel_mask(int r0, int k0, int tid, bool keep_ge, bool unit, d2_t (&v)[4]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    int r[2], k[2];
+    if (KC) {
+      r[0] = r[1] = r0 + (tid >> 3) + 32 * q;
+      k[0] = k0 + 2 * (tid & 7);
+      k[1] = k[0] + 1;
+    } else {
+      r[0] = r0 + 2 * (tid & 63);
+      r[1] = r[0] + 1;
+      k[0] = k[1] = k0 + (tid >> 6) + 4 * q;
+    }
+    double e0 = v[q].x, e1 = v[q].y;
+    if (keep_ge ? (k[0] < r[0]) : (k[0] > r[0])) e0 = 0.0;
+    if (keep_ge ? (k[1] < r[1]) : (k[1] > r[1])) e1 = 0.0;
+    if (unit) {
+      if (k[0] == r[0]) e0 = 1.0;
+      if (k[1] == r[1]) e1 = 1.0;
+    }
+    v[q].x = e0;
+    v[q].y = e1;
+  }
+}
+
+template <bool KC>
+__device__ __forceinline__ void panel_store(double* __restrict__ L, int tid, const d2_t (&v)[4]) {
+  if (KC) {
+    const int kp = tid & 7, rb = tid >> 3;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *(d2_t*)&L[(rb + 32 * q) * SK + 2 * kp] = v[q];
+  } else {
+    const int rp = tid & 63, kb = tid >> 6;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *(d2_t*)&L[(kb + 4 * q) * SR + 2 * rp] = v[q];
+  }
+}
+
+// fragment for MFMA k-steps 2u and 2u+1 of 16-row sub-block `row` (panel row index of this lane).
+// k-step s = 2u+e of lane group g = lane>>4 consumes physical k = 8u + 2g + e in BOTH operands.
+template <bool KC>
+__device__ __forceinline__ d2_t frag_read(const double* __restrict__ L, int row, int u, int g) {
+  if (KC) {
+    return *(const d2_t*)&L[row * SK + 8 * u + 2 * g];
+  } else {
+    d2_t f;
+    f.x = L[(8 * u + 2 * g) * SR + row];
+    f.y = L[(8 * u + 2 * g + 1) * SR + row];
+    return f;
+  }
+}
+
+__device__ __forceinline__ void tile_of(const GemmArgs& p, int t, int& ti, int& tj) {
+  if (p.out_uplo < 0) {
+    const int in_group = GROUP_M * p.tiles_n;
+    const int group = t / in_group;
+    const int first_m = group * GROUP_M;
+    const int gsz = min(p.tiles_m - first_m, GROUP_M);
+    const int loc = t - group * in_group;
+    ti = first_m + loc % gsz;
+    tj = loc / gsz;
+  } else {
+    // t enumerates pairs (lo <= hi): t = hi*(hi+1)/2 + lo
+    int hi = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((int64_t)hi * (hi + 1) / 2 > t) --hi;
+    while ((int64_t)(hi + 1) * (hi + 2) / 2 <= t) ++hi;
+    const int lo = t - (int)((int64_t)hi * (hi + 1) / 2);
+    if (p.out_uplo == CAPI_UPPER) { ti = lo; tj = hi; } else { ti = hi; tj = lo; }
+  }
+}
+
+template <bool AK, bool BKC>
+__global__ __launch_bounds__(NTHREADS, 2) void dgemm_tile_kernel(const GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int wm = wave & 1, wn = wave >> 1;
+
+  // XCD-aware re-deal: consecutive pids share an XCD (dispatcher deals blockIdx round-robin over 8 XCDs)
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, qq = nblk >> 3, rr = nblk & 7;
+  const int pid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const int z = pid / p.ntiles;
+  int ti, tj;
+  tile_of(p, pid - z * p.ntiles, ti, tj);
+  const int i0 = ti * BM, j0 = tj * BN;
+
+  // k-range of this tile
+  int klo = 0, khi = p.K;
+  if (p.tri_side == CAPI_LEFT) {
+    if (p.tri_eff_upper) klo = i0; else khi = min(p.K, i0 + BM);
+  } else if (p.tri_side == CAPI_RIGHT) {
+    if (p.tri_eff_upper) khi = min(p.K, j0 + BN); else klo = j0;
+  }
+  if (p.splitk > 1) {
+    klo = max(klo, z * p.k_per_split);
+    khi = min(khi, (z + 1) * p.k_per_split);
+  }
+  const int ntk = khi > klo ? (khi - klo + BK - 1) / BK : 0;
+  const bool maskA = p.tri_side == CAPI_LEFT, maskB = p.tri_side == CAPI_RIGHT;
+  const bool keep_ge = (p.tri_side == CAPI_LEFT) == (p.tri_eff_upper != 0);
+
+  d4_t acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (d4_t){0.0, 0.0, 0.0, 0.0};
+
+  d2_t ra[4], rb[4];
+  if (ntk > 0) {
+    panel_load<AK>(p.A, p.lda, i0, p.M, klo, khi, tid, p.a_vec, ra);
+    panel_load<BKC>(p.B, p.ldb, j0, p.N, klo, khi, tid, p.b_vec, rb);
+    if (maskA && klo < i0 + BM && klo + BK > i0) panel_mask<AK>(i0, klo, tid, keep_ge, p.tri_unit, ra);
+    if (maskB && klo < j0 + BN && klo + BK > j0) panel_mask<BKC>(j0, klo, tid, keep_ge, p.tri_unit, rb);
+    panel_store<AK>(lds, tid, ra);
+    panel_store<BKC>(lds + TILE_LDS, tid, rb);
+  }
+  __syncthreads();
+
+  for (int t = 0; t < ntk; ++t) {
+    const double* La = lds + (t & 1) * STAGE_LDS;
+    const double* Lb = La + TILE_LDS;
+    const int kn = klo + (t + 1) * BK;
+    const bool more = (t + 1 < ntk);
+    if (more) {
+      panel_load<AK>(p.A, p.lda, i0, p.M, kn, khi, tid, p.a_vec, ra);
+      panel_load<BKC>(p.B, p.ldb, j0, p.N, kn, khi, tid, p.b_vec, rb);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      d2_t af[4], bf[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) af[a] = frag_read<AK>(La, wm * 64 + a * 16 + r16, u, g);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) bf[b] = frag_read<BKC>(Lb, wn * 64 + b * 16 + r16, u, g);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].x, af[a].x, acc[a][b], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].y, af[a].y, acc[a][b], 0, 0, 0);
+    }
+    if (more) {
+      if (maskA && kn < i0 + BM && kn + BK > i0) panel_mask<AK>(i0, kn, tid, keep_ge, p.tri_unit, ra);
+      if (maskB && kn < j0 + BN && kn + BK > j0) panel_mask<BKC>(j0, kn, tid, keep_ge, p.tri_unit, rb);
+      double* Na = lds + ((t + 1) & 1) * STAGE_LDS;
+      panel_store<AK>(Na, tid, ra);
+      panel_store<BKC>(Na + TILE_LDS, tid, rb);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: lane holds C[i = ..+r16][j = ..+g+4*reg]; 16 lanes -> 128 contiguous bytes of one column
+  const bool to_slab = p.splitk > 1;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int i = i0 + wm * 64 + a * 16 + r16;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int j = j0 + wn * 64 + b * 16 + g + 4 * reg;
+        bool ok = (i < p.M) && (j < p.N);
+        if (p.out_uplo == CAPI_UPPER) ok = ok && (i <= j);
+        if (p.out_uplo == CAPI_LOWER) ok = ok && (i >= j);
+        if (ok) {
+          const double v = acc[a][b][reg];
+          if (to_slab) {
+            p.slab[(int64_t)z * p.slab_stride + i + (int64_t)j * p.slab_ld] = v;
+          } else {
+            double* c = p.C + i + (int64_t)j * p.ldc;
+            double r = p.alpha * v;
+            if (p.beta != 0.0) r += p.beta * (*c);
+            *c = r;
+          }
+        }
+      }
+    }
+  }
+}
+
+// C(part) <- alpha * sum_z slab[z] + beta*C   (fixed summation order: bit-reproducible)
+__global__ void splitk_reduce_kernel(const double* __restrict__ slab, int64_t slab_ld, int64_t slab_stride, int splitk,
+                                     double* __restrict__ C, int64_t ldc, int M, int N, double alpha, double beta, int out_uplo) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  for (int j = blockIdx.y; j < N; j += gridDim.y) {
+    if (out_uplo == CAPI_UPPER && i > j) continue;
+    if (out_uplo == CAPI_LOWER && i < j) continue;
+    double s = 0.0;
+    for (int z = 0; z < splitk; ++z) s += slab[(int64_t)z * slab_stride + i + (int64_t)j * slab_ld];
+    double* c = C + i + (int64_t)j * ldc;
+    double r = alpha * s;
+    if (beta != 0.0) r += beta * (*c);
+    *c = r;
+  }
+}
+
+// scale-only path for alpha == 0 or K == 0:  C(part) <- beta*C
+__global__ void scale_kernel(double* __restrict__ C, int64_t ldc, int M, int N, double beta, int out_uplo) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  for (int j = blockIdx.y; j < N; j += gridDim.y) {
+    if (out_uplo == CAPI_UPPER && i > j) continue;
+    if (out_uplo == CAPI_LOWER && i < j) continue;
+    double* c = C + i + (int64_t)j * ldc;
+    *c = beta == 0.0 ? 0.0 : beta * (*c);
+  }
+}
+
+typedef void (*gemm_kernel_t)(const GemmArgs);
+
+int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool allow_splitk) {
+  if (p.M <= 0 || p.N <= 0) return CAPI_OK;
+  hipStream_t s = h->stream;
+  if (p.K <= 0 || p.alpha == 0.0) {
+    if (p.beta == 1.0 && p.tri_side < 0) return CAPI_OK;
+    dim3 grid((unsigned)cdiv(p.M, 256), (unsigned)(p.N < 65535 ? p.N : 65535));
+    hipLaunchKernelGGL(scale_kernel, grid, dim3(256), 0, s, p.C, p.ldc, p.M, p.N, p.tri_side < 0 ? p.beta : 0.0, p.out_uplo);
+    CAPI_HIP_CHECK(h, hipGetLastError());
+    return CAPI_OK;
+  }
+  p.tiles_m = (int)cdiv(p.M, BM);
+  p.tiles_n = (int)cdiv(p.N, BN);
+  p.ntiles = p.out_uplo < 0 ? p.tiles_m * p.tiles_n : (int)((int64_t)p.tiles_m * (p.tiles_m + 1) / 2);
+  p.a_vec = (((uintptr_t)p.A & 15) == 0) && ((p.lda & 1) == 0);
+  p.b_vec = (((uintptr_t)p.B & 15) == 0) && ((p.ldb & 1) == 0);
+  p.splitk = 1;
+  p.k_per_split = p.K;
+  p.slab = nullptr;
+  p.slab_ld = p.slab_stride = 0;
+  // split-K only for small outputs with a long K (CholeskyQR2 Gram matrices)
+  const int target = 4 * h->num_cu;
+  if (allow_splitk && p.tri_side < 0 && p.ntiles * 2 <= target && p.K >= 4096) {
+    int sk = target / p.ntiles;
+    int max_sk = p.K / 512;  // at least 512-deep slices
+    sk = sk < max_sk ? sk : max_sk;
+    if (sk > 1) {
+      int kps = (int)cdiv(cdiv(p.K, sk), BK) * BK;
+      sk = (int)cdiv(p.K, kps);
+      if (sk > 1) {
+        p.splitk = sk;
+        p.k_per_split = kps;
+        p.slab_ld = p.M;
+        p.slab_stride = (int64_t)p.M * p.N;
+        void* ws;
+        int rc = capi_ws_get(h, sizeof(double) * (size_t)p.slab_stride * sk, &ws);
+        if (rc != CAPI_OK) return rc;
+        p.slab = (double*)ws;
+      }
+    }
+  }
+  gemm_kernel_t k = ak ? (bkc ? dgemm_tile_kernel<true, true> : dgemm_tile_kernel<true, false>)
+                       : (bkc ? dgemm_tile_kernel<false, true> : dgemm_tile_kernel<false, false>);
+  const size_t lds_bytes = sizeof(double) * 2 * STAGE_LDS;
+  const int64_t nblk = (int64_t)p.ntiles * p.splitk;
+  CAPI_REQUIRE(h, nblk < (int64_t)1 << 31, "too many tiles");
+  hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(NTHREADS), lds_bytes, s, p);
+  CAPI_HIP_CHECK(h, hipGetLastError());
+  if (p.splitk > 1) {
+    dim3 grid((unsigned)cdiv(p.M, 256), (unsigned)(p.N < 65535 ? p.N : 65535));
+    hipLaunchKernelGGL(splitk_reduce_kernel, grid, dim3(256), 0, s, p.slab, p.slab_ld, p.slab_stride, p.splitk, p.C, p.ldc,
+                       p.M, p.N, p.alpha, p.beta, p.out_uplo);
+    CAPI_HIP_CHECK(h, hipGetLastError());
+  }
+  return CAPI_OK;
+}
+
+bool ok01(int v) { return v == 0 || v == 1; }
+
+// ---- register-resident MFMA loop: the measured fp64 matrix peak of this device -----------------------
+__global__ __launch_bounds__(256) void mfma_f64_peak_kernel(double* out, int iters) {
+  d4_t acc[8];
+  const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) acc[q] = (d4_t){0.0, 0.0, 0.0, 0.0};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[q], 0, 0, 0);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) s += acc[q][0] + acc[q][1] + acc[q][2] + acc[q][3];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+}  // namespace
+
+extern "C" {
+
+int capi_dgemm(capi_handle_t h, int transA, int transB, int64_t m, int64_t n, int64_t k, double alpha,
+               const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc) {
+  CAPI_REQUIRE(h, h, "null handle");
+  CAPI_REQUIRE(h, ok01(transA) && ok01(transB), "transpose code");
+  CAPI_REQUIRE(h, m >= 0 && n >= 0 && k >= 0 && m < (1LL << 31) && n < (1LL << 31) && k < (1LL << 31), "dims");
+  if (m == 0 || n == 0) return CAPI_OK;
+  CAPI_REQUIRE(h, C && ldc >= m, "C/ldc");
+  if (k > 0) {
+    CAPI_REQUIRE(h, A && B, "null operand");
+    CAPI_REQUIRE(h, lda >= (transA ? k : m) && ldb >= (transB ? n : k), "lda/ldb");
+  }
+  GemmArgs p{};
+  p.A = A; p.B = B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.M = (int)m; p.N = (int)n; p.K = (int)k; p.alpha = alpha; p.beta = beta;
+  p.out_uplo = -1; p.tri_side = -1;
+  return launch_gemm(h, transA == CAPI_TRANS, transB == CAPI_NOTRANS, p, true);
+}
+
+int capi_dgemmt(capi_handle_t h, int uplo, int transA, int transB, int64_t n, int64_t k, double alpha,
+                const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc) {
+  CAPI_REQUIRE(h, h, "null handle");
+  CAPI_REQUIRE(h, ok01(uplo) && ok01(transA) && ok01(transB), "enum code");
+  CAPI_REQUIRE(h, n >= 0 && k >= 0 && n < (1LL << 31) && k < (1LL << 31), "dims");
+  if (n == 0) return CAPI_OK;
+  CAPI_REQUIRE(h, C && ldc >= n, "C/ldc");
+  if (k > 0) {
+    CAPI_REQUIRE(h, A && B, "null operand");
+    CAPI_REQUIRE(h, lda >= (transA ? k : n) && ldb >= (transB ? n : k), "lda/ldb");
+  }
+  GemmArgs p{};
+  p.A = A; p.B = B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.M = (int)n; p.N = (int)n; p.K = (int)k; p.alpha = alpha; p.beta = beta;
+  p.out_uplo = uplo; p.tri_side = -1;
+  return launch_gemm(h, transA == CAPI_TRANS, transB == CAPI_NOTRANS, p, true);
+}
+
+int capi_dsyrk(capi_handle_t h, int uplo, int trans, int64_t n, int64_t k, double alpha,
+               const double* A, int64_t lda, double beta, double* C, int64_t ldc) {
+  CAPI_REQUIRE(h, h, "null handle");
+  CAPI_REQUIRE(h, ok01(trans), "transpose code");
+  // Trans: C = A^T A (A is k x n);  NoTrans: C = A A^T (A is n x k)
+  return capi_dgemmt(h, uplo, trans, trans == CAPI_TRANS ? CAPI_NOTRANS : CAPI_TRANS, n, k, alpha, A, lda, A, lda, beta, C, ldc);
+}
+
+int capi_dtrmm_oop(capi_handle_t h, int side, int uplo, int trans, int diag, int64_t m, int64_t n, double alpha,
+                   const double* T, int64_t ldt, const double* B, int64_t ldb, double* C, int64_t ldc) {
+  CAPI_REQUIRE(h, h, "null handle");
+  CAPI_REQUIRE(h, ok01(side) && ok01(uplo) && ok01(trans) && ok01(diag), "enum code");
+  CAPI_REQUIRE(h, m >= 0 && n >= 0 && m < (1LL << 31) && n < (1LL << 31), "dims");
+  if (m == 0 || n == 0) return CAPI_OK;
+  const int64_t nt = side == CAPI_LEFT ? m : n;
+  CAPI_REQUIRE(h, T && B && C && ldt >= nt && ldb >= m && ldc >= m, "operands");
+  CAPI_REQUIRE(h, (const double*)C != B, "out-of-place trmm: C aliases B");
+  GemmArgs p{};
+  p.C = C; p.ldc = ldc; p.M = (int)m; p.N = (int)n; p.K = (int)nt; p.alpha = alpha; p.beta = 0.0;
+  p.out_uplo = -1;
+  p.tri_side = side;
+  p.tri_eff_upper = ((uplo == CAPI_UPPER) != (trans == CAPI_TRANS));
+  p.tri_unit = diag == CAPI_UNIT;
+  if (side == CAPI_LEFT) {  // C = alpha op(T) B : A-operand = T (transA = trans), B-operand = B (NoTrans)
+    p.A = T; p.lda = ldt; p.B = B; p.ldb = ldb;
+    return launch_gemm(h, trans == CAPI_TRANS, true, p, false);
+  } else {                  // C = alpha B op(T) : A-operand = B (NoTrans), B-operand = T (transB = trans)
+    p.A = B; p.lda = ldb; p.B = T; p.ldb = ldt;
+    return launch_gemm(h, false, trans == CAPI_NOTRANS, p, false);
+  }
+}
+
+int capi_dtrmm(capi_handle_t h, int side, int uplo, int trans, int diag, int64_t m, int64_t n, double alpha,
+               const double* T, int64_t ldt, double* B, int64_t ldb) {
+  CAPI_REQUIRE(h, h, "null handle");
+  if (m <= 0 || n <= 0) return m < 0 || n < 0 ? CAPI_EINVAL : CAPI_OK;
+  void* ws;
+  int rc = capi_ws_get(h, sizeof(double) * (size_t)m * (size_t)n, &ws);
+  if (rc != CAPI_OK) return rc;
+  rc = capi_dtrmm_oop(h, side, uplo, trans, diag, m, n, alpha, T, ldt, B, ldb, (double*)ws, m);
+  if (rc != CAPI_OK) return rc;
+  CAPI_HIP_CHECK(h, hipMemcpy2DAsync(B, sizeof(double) * ldb, ws, sizeof(double) * m, sizeof(double) * m, n,
+                                     hipMemcpyDeviceToDevice, h->stream));
+  return CAPI_OK;
+}
+
+int capi_mfma_f64_peak(capi_handle_t h, int iters, double* tflops) {
+  CAPI_REQUIRE(h, h && tflops && iters > 0, "args");
+  const int blocks = h->num_cu * 2;  // 2 x 4 waves per CU = 2 waves per SIMD
+  double* out;
+  CAPI_HIP_CHECK(h, hipMalloc((void**)&out, sizeof(double) * blocks * 256));
+  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, h->stream, out, 16);  // warm-up
+  CAPI_HIP_CHECK(h, hipEventRecord(h->ev0, h->stream));
+  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, h->stream, out, iters);
+  CAPI_HIP_CHECK(h, hipEventRecord(h->ev1, h->stream));
+  CAPI_HIP_CHECK(h, hipEventSynchronize(h->ev1));
+  float ms = 0;
+  CAPI_HIP_CHECK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  CAPI_HIP_CHECK(h, hipFree(out));
+  const double flops = (double)blocks * 4.0 /*waves*/ * (double)iters * 8.0 * 2048.0;
+  *tflops = flops / ((double)ms * 1e-3) / 1e12;
+  return CAPI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,157 @@
+/*
+ * capital_hip.h -- C-ABI of libcapital_hip.so: the MI355X (gfx950) replacement for
+ * the BLAS/LAPACK/MPI layer underneath huttered40/capital's recursive Cholesky
+ * (cholinv) and CA-CholeskyQR2 (cacqr).
+ *
+ * This header IS the drop-in boundary.  Each entry point names the reference
+ * interface it replaces (paths relative to the reference root).  All pointers
+ * called A/B/C/T/data are DEVICE pointers (HBM); matrices are column-major fp64
+ * exactly as the reference passes them to MKL.  Nothing here takes or returns a
+ * C++ or torch type.  Every call is asynchronous on the handle's HIP stream
+ * unless stated otherwise and returns a capi_status (0 = ok).
+ *
+ * Enum codes are the reference's own (src/blas/engine.h:23-46, src/lapack/engine.h:23-36):
+ *   Transpose NoTrans=0 Trans=1 | Side Left=0 Right=1 | UpLo Lower=0 Upper=1 | Diag NonUnit=0 Unit=1
+ */
+#ifndef CAPITAL_HIP_H_
+#define CAPITAL_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct capi_handle_s* capi_handle_t;
+typedef struct capi_comm_s*   capi_comm_t;
+
+enum capi_status {
+  CAPI_OK = 0,
+  CAPI_EINVAL = -1,   /* bad argument (dims, enum code, null pointer, alignment) */
+  CAPI_EHIP = -2,     /* a HIP runtime call failed; see capi_last_error() */
+  CAPI_ENOMEM = -3,
+  CAPI_ECOMM = -4,    /* RCCL failure or communicator misuse */
+  CAPI_ENOTSPD = -5   /* potrf met a non-positive pivot (see capi_get_info) */
+};
+enum { CAPI_NOTRANS = 0, CAPI_TRANS = 1 };
+enum { CAPI_LEFT = 0, CAPI_RIGHT = 1 };
+enum { CAPI_LOWER = 0, CAPI_UPPER = 1 };
+enum { CAPI_NONUNIT = 0, CAPI_UNIT = 1 };
+/* matrix structure policies, src/matrix/structure.h:8-72 */
+enum { CAPI_RECT = 0, CAPI_UPPERTRI = 1, CAPI_LOWERTRI = 2 };
+
+/* ---- lifecycle / memory (replaces new[]/memcpy inside matrix<>, src/matrix/structure.hpp:4-26) ---- */
+int  capi_version(void);
+int  capi_device_count(void);
+int  capi_create(capi_handle_t* h, int device);                 /* owns a new non-blocking stream */
+int  capi_create_on_stream(capi_handle_t* h, int device, void* hip_stream); /* borrows the caller's stream */
+int  capi_destroy(capi_handle_t h);
+void* capi_get_stream(capi_handle_t h);
+const char* capi_last_error(capi_handle_t h);
+int  capi_malloc(capi_handle_t h, void** dptr, size_t bytes);
+int  capi_free(capi_handle_t h, void* dptr);
+int  capi_memset_async(capi_handle_t h, void* dptr, int value, size_t bytes);
+int  capi_memcpy_h2d(capi_handle_t h, void* dst, const void* src, size_t bytes);   /* synchronous */
+int  capi_memcpy_d2h(capi_handle_t h, void* dst, const void* src, size_t bytes);   /* synchronous */
+int  capi_memcpy_d2d_async(capi_handle_t h, void* dst, const void* src, size_t bytes);
+int  capi_sync(capi_handle_t h);
+/* grow the handle's private workspace (used by in-place trmm, split-K slabs, potrf) ahead of time */
+int  capi_reserve_workspace(capi_handle_t h, size_t bytes);
+
+/* ---- BLAS layer: replaces blas::engine::_gemm/_trmm/_syrk (src/blas/interface.h:58-66,
+ *      src/blas/interface.hpp:43-97 -> cblas_dgemm/dtrmm/dsyrk) ---- */
+/* C <- alpha*op(A)*op(B) + beta*C  (K1-K3; call sites summa.hpp:28,139,144; cacqr.hpp:95,144) */
+int capi_dgemm(capi_handle_t h, int transA, int transB, int64_t m, int64_t n, int64_t k, double alpha,
+               const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc);
+/* C(uplo) <- alpha*A^T*A + beta*C (trans=Trans, A is k x n) or alpha*A*A^T (NoTrans, A is n x k)
+ * (K7; call site cacqr.hpp:15).  Only the `uplo` triangle of C is read or written. */
+int capi_dsyrk(capi_handle_t h, int uplo, int trans, int64_t n, int64_t k, double alpha,
+               const double* A, int64_t lda, double beta, double* C, int64_t ldc);
+/* Triangular-output GEMM: C(uplo) <- alpha*op(A)*op(B) + beta*C, C is n x n.  This is what the
+ * reference's summa "syrk" (summa.hpp:111-158) needs: it runs a full cblas_dgemm there because a
+ * rank's two operands are different blocks; computing only the needed triangle halves the work. */
+int capi_dgemmt(capi_handle_t h, int uplo, int transA, int transB, int64_t n, int64_t k, double alpha,
+                const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc);
+/* B <- alpha*op(T)*B (Left) or alpha*B*op(T) (Right); T triangular, only its `uplo` triangle is read
+ * (K4-K6; call sites summa.hpp:64,71; cacqr.hpp:25,185).  In place, as cblas_dtrmm. */
+int capi_dtrmm(capi_handle_t h, int side, int uplo, int trans, int diag, int64_t m, int64_t n, double alpha,
+               const double* T, int64_t ldt, double* B, int64_t ldb);
+/* Out-of-place form used on the hot path: C <- alpha*op(T)*B or alpha*B*op(T); C must not alias B. */
+int capi_dtrmm_oop(capi_handle_t h, int side, int uplo, int trans, int diag, int64_t m, int64_t n, double alpha,
+                   const double* T, int64_t ldt, const double* B, int64_t ldb, double* C, int64_t ldc);
+/* B <- alpha*op(T)^-1*B or alpha*B*op(T)^-1.  Not in the reference (it forms trtri+trmm instead,
+ * SURVEY.md quick facts); named by BASELINE.json north_star. */
+int capi_dtrsm(capi_handle_t h, int side, int uplo, int trans, int diag, int64_t m, int64_t n, double alpha,
+               const double* T, int64_t ldt, double* B, int64_t ldb);
+
+/* ---- LAPACK layer: replaces lapack::engine::_potrf/_trtri (src/lapack/interface.h:49-53,
+ *      src/lapack/interface.hpp:30-58 -> LAPACKE_dpotrf/dtrtri, column-major) ---- */
+/* The LAPACK `info` the reference discards is kept on the device; capi_get_info() synchronises and
+ * returns it (0, or 1-based index of the first non-positive pivot / zero diagonal). */
+int capi_dpotrf(capi_handle_t h, int uplo, int64_t n, double* A, int64_t lda);
+int capi_dtrtri(capi_handle_t h, int uplo, int diag, int64_t n, double* A, int64_t lda);
+/* Fused base case of cholinv (cholinv/policy.h:190-205: potrf, memcpy, trtri): A(upper) -> R in place,
+ * Rinv <- R^-1 (upper); strictly-lower parts of both outputs are zeroed (cyclic_to_local, util.hpp:131-164). */
+int capi_dpotrf_trtri(capi_handle_t h, int64_t n, double* A, int64_t lda, double* Rinv, int64_t ldi);
+int capi_get_info(capi_handle_t h, int* info);
+int capi_reset_info(capi_handle_t h);
+
+/* ---- data movement: replaces serialize<> (src/matrix/serialize.hpp:12-150), the pack/unpack and
+ *      axpy loops of summa (summa.hpp:33,135,147-153,216-217) and util::remove_triangle (util.hpp:266-318) ---- */
+/* sub-block copy between two (possibly packed-triangular) local layouts; ranges as in serialize<>::invoke */
+int capi_serialize(capi_handle_t h, int src_struct, int dst_struct,
+                   const double* src, int64_t sdimX, int64_t sdimY, double* dst, int64_t ddimX, int64_t ddimY,
+                   int64_t ssx, int64_t sex, int64_t ssy, int64_t sey, int64_t dsx, int64_t dex, int64_t dsy, int64_t dey);
+/* B <- A for an m x n block; part: 0 all, 1 upper triangle incl. diagonal, 2 lower incl. diagonal */
+int capi_dlacpy(capi_handle_t h, int part, int64_t m, int64_t n, const double* A, int64_t lda, double* B, int64_t ldb);
+/* zero the strictly lower (uplo=Upper keeps upper) or strictly upper part of an n x n block */
+int capi_dtrizero(capi_handle_t h, int keep_uplo, int64_t n, double* A, int64_t lda);
+/* y <- beta*y + x over count elements (M3) */
+int capi_daxpby(capi_handle_t h, int64_t count, double beta, const double* x, double* y);
+/* zero by GLOBAL index parity: local (i,j) is global (px+i*P, py+j*P); dir 'U' zeroes gy>gx, 'L' zeroes gy<gx */
+int capi_remove_triangle(capi_handle_t h, char dir, double* A, int64_t dimX, int64_t dimY, int64_t px, int64_t py, int64_t P);
+/* element-cyclic gather/scatter of the base case (util.hpp:56-230): pieces[r] (r = x*d + y... see DESIGN.md)
+ * are d*d local blocks of rows_local x cols_local; cyclic is the (rows_local*d) x (cols_local*d) aggregate */
+int capi_block_to_cyclic(capi_handle_t h, const double* blocked, double* cyclic, int64_t rows_local, int64_t cols_local, int64_t d);
+int capi_cyclic_to_block(capi_handle_t h, double* blocked, const double* cyclic, int64_t rows_local, int64_t cols_local, int64_t d);
+
+/* ---- generators: replaces rect::_distribute_* (src/matrix/structure.hpp:36-129), bit-identical output ---- */
+int capi_distribute_symmetric(capi_handle_t h, double* data, int64_t dimX, int64_t dimY, int64_t gdimX, int64_t gdimY,
+                              int64_t px, int64_t py, int64_t PX, int64_t PY, int64_t key, int diag_dominant);
+int capi_distribute_random(capi_handle_t h, double* data, int64_t dimX, int64_t dimY, int64_t gdimX, int64_t gdimY,
+                           int64_t px, int64_t py, int64_t PX, int64_t PY, int64_t key);
+int capi_distribute_identity(capi_handle_t h, double* data, int64_t dimX, int64_t dimY, int64_t gdimX, int64_t gdimY,
+                             int64_t px, int64_t py, int64_t PX, int64_t PY, double val);
+
+/* ---- residual reductions: replaces util::residual_local's local sums (src/util/util.hpp:25-53) ---- */
+/* out[0] = sum (X[i]-Y[i])^2 over the selected part, out[1] = sum Y[i]^2; part as capi_dlacpy; out is HOST memory (synchronous) */
+int capi_diff_norms(capi_handle_t h, int part, int64_t m, int64_t n, const double* X, int64_t ldx, const double* Y, int64_t ldy, double* out2);
+
+/* ---- collectives: replaces the MPI calls of summa/util/policy (C1-C10) with RCCL on the
+ *      handle's stream.  A communicator is created from a 128-byte RCCL unique id that rank 0 obtains with
+ *      capi_comm_unique_id() and the launcher ships to the other ranks (torch.distributed store, MPI, a file). ---- */
+int capi_comm_load_rccl(const char* librccl_path);              /* optional: choose the librccl.so to bind (default: search) */
+int capi_comm_unique_id(void* id128);
+int capi_comm_init_rank(capi_comm_t* comm, capi_handle_t h, int nranks, const void* id128, int rank);
+int capi_comm_split(capi_comm_t parent, int color, int key, capi_comm_t* child);       /* MPI_Comm_split, topology.h:28-59,84-138 */
+int capi_comm_rank(capi_comm_t c, int* rank);
+int capi_comm_size(capi_comm_t c, int* size);
+int capi_comm_destroy(capi_comm_t c);
+int capi_bcast(capi_comm_t c, double* buf, int64_t count, int root);                   /* MPI_Bcast, summa.hpp:185,193 */
+int capi_allreduce_sum(capi_comm_t c, double* buf, int64_t count);                     /* MPI_Allreduce(IN_PLACE,SUM), summa.hpp:236 */
+int capi_reduce_sum(capi_comm_t c, const double* send, double* recv, int64_t count, int root);  /* MPI_Reduce, cacqr.hpp:98 */
+int capi_allgather(capi_comm_t c, const double* send, double* recv, int64_t count_per_rank);   /* MPI_Allgather, policy.h:176 */
+int capi_sendrecv_replace(capi_comm_t c, double* buf, int64_t count, int peer, double* staging); /* MPI_Sendrecv_replace, util.hpp:240 */
+
+/* ---- measurement helpers ---- */
+/* register-resident v_mfma_f64_16x16x4_f64 loop on every CU: returns achieved TFLOP/s (synchronous) */
+int capi_mfma_f64_peak(capi_handle_t h, int iters, double* tflops);
+/* HIP-event timer on the handle's stream */
+int capi_timer_start(capi_handle_t h);
+int capi_timer_stop_ms(capi_handle_t h, float* ms);              /* synchronises */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAPITAL_HIP_H_ */

@@ -1,0 +1,167 @@
+"""GPU parity: BLAS-level C-ABI (capi_dgemm/dgemmt/dsyrk/dtrmm/dtrsm) against the CPU oracle's
+restatement of cblas_dgemm/dsyrk/dtrmm (reference src/blas/interface.hpp:43-97).
+Tolerance: fp64, |gpu - oracle| <= 1e-13 * k * max|entries| (summation-order differences only)."""
+import itertools
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(rng, m, n):
+    return np.asfortranarray(rng.uniform(-1, 1, size=(m, n)))
+
+
+def _check(got, ref, k, scale=1.0):
+    tol = 1e-14 * max(k, 16) * max(scale, 1.0)
+    err = np.abs(got - ref).max() if got.size else 0.0
+    assert err <= tol, f"max err {err:.3e} > tol {tol:.3e}"
+
+
+def test_mfma_identity_layout(hip, oracle):
+    """A = I with an ASYMMETRIC B: catches a transposed accumulator map (f64 MFMA C/D layout)."""
+    from capital_amd import capi
+    n = 128
+    A = np.asfortranarray(np.eye(n))
+    B = np.asfortranarray(np.arange(n * n, dtype=np.float64).reshape(n, n) % 97 + np.arange(n)[:, None] * 0.5)
+    dA, dB, dC = capi.to_device(A), capi.to_device(B), capi.zeros(n, n)
+    hip.call("capi_dgemm", 0, 0, n, n, n, 1.0, capi.ptr(dA), n, capi.ptr(dB), n, 0.0, capi.ptr(dC), n)
+    np.testing.assert_array_equal(capi.to_host(dC), B)
+    hip.call("capi_dgemm", 1, 0, n, n, n, 1.0, capi.ptr(dB), n, capi.ptr(dA), n, 0.0, capi.ptr(dC), n)
+    np.testing.assert_array_equal(capi.to_host(dC), B.T)
+
+
+@pytest.mark.parametrize("ta,tb", list(itertools.product((0, 1), (0, 1))))
+@pytest.mark.parametrize("m,n,k,pad", [(128, 128, 64, 0), (200, 150, 77, 0), (257, 131, 1000, 3), (1, 1, 1, 0), (64, 300, 16, 1), (513, 129, 130, 0)])
+def test_dgemm(hip, oracle, ta, tb, m, n, k, pad):
+    from capital_amd import capi
+    rng = np.random.default_rng(m * 7 + n * 3 + k + ta * 2 + tb)
+    ar, ac = (k, m) if ta else (m, k)
+    br, bc = (n, k) if tb else (k, n)
+    A = _rand(rng, ar + pad, ac)[:ar, :]          # ld = ar + pad
+    B = _rand(rng, br + pad, bc)[:br, :]
+    Cm = _rand(rng, m + pad, n)[:m, :]
+    Af, Bf, Cf = _rand(rng, ar + pad, ac), _rand(rng, br + pad, bc), _rand(rng, m + pad, n)
+    A, B, Cm = Af[:ar, :], Bf[:br, :], Cf[:m, :]
+    ref = np.asfortranarray(Cm.copy())
+    oracle.dgemm(ta, tb, 0.75, np.asfortranarray(A), np.asfortranarray(B), -0.5, ref)
+    dA, dB, dC = capi.to_device(Af), capi.to_device(Bf), capi.to_device(Cf)
+    hip.call("capi_dgemm", ta, tb, m, n, k, 0.75, capi.ptr(dA), ar + pad, capi.ptr(dB), br + pad, -0.5, capi.ptr(dC), m + pad)
+    got = capi.to_host(dC)
+    _check(got[:m, :], ref, k)
+    if pad:  # rows beyond m must be untouched
+        np.testing.assert_array_equal(got[m:, :], Cf[m:, :])
+
+
+def test_dgemm_beta0_ignores_nan(hip, oracle):
+    from capital_amd import capi
+    rng = np.random.default_rng(5)
+    m = n = k = 96
+    A, B = _rand(rng, m, k), _rand(rng, k, n)
+    dC = capi.to_device(np.full((m, n), np.nan))
+    hip.call("capi_dgemm", 0, 0, m, n, k, 1.0, capi.ptr(capi.to_device(A)), m, capi.ptr(capi.to_device(B)), k, 0.0, capi.ptr(dC), m)
+    _check(capi.to_host(dC), A @ B, k)
+
+
+def test_dgemm_unaligned_pointer(hip, oracle):
+    """Odd element offsets defeat the 16-byte fast path; results must not change."""
+    from capital_amd import capi
+    rng = np.random.default_rng(6)
+    m, n, k, ld = 130, 140, 150, 201
+    Af, Bf = _rand(rng, ld, 256), _rand(rng, ld, 256)
+    dA, dB, dC = capi.to_device(Af), capi.to_device(Bf), capi.zeros(m, n)
+    offA, offB = 1 + 3 * ld, 5 + 1 * ld
+    A = Af.ravel(order="F")[offA:offA + ld * k].reshape((ld, k), order="F")[:m, :]   # NoTrans m x k
+    B = Bf.ravel(order="F")[offB:offB + ld * n].reshape((ld, n), order="F")[:k, :]
+    hip.call("capi_dgemm", 0, 0, m, n, k, 1.0, capi.ptr(dA) + 8 * offA, ld, capi.ptr(dB) + 8 * offB, ld, 0.0, capi.ptr(dC), m)
+    _check(capi.to_host(dC), A @ B, k)
+
+
+@pytest.mark.parametrize("uplo", (0, 1))
+@pytest.mark.parametrize("trans", (0, 1))
+@pytest.mark.parametrize("n,k", [(128, 128), (300, 77), (1, 5), (515, 260)])
+def test_dsyrk(hip, oracle, uplo, trans, n, k):
+    from capital_amd import capi
+    rng = np.random.default_rng(n + k + uplo + 2 * trans)
+    A = _rand(rng, k, n) if trans else _rand(rng, n, k)
+    Cm = _rand(rng, n, n)
+    ref = Cm.copy(order="F")
+    oracle.dsyrk(uplo, trans, -1.0, A, 1.0, ref)
+    dA, dC = capi.to_device(A), capi.to_device(Cm)
+    hip.call("capi_dsyrk", uplo, trans, n, k, -1.0, capi.ptr(dA), A.shape[0], 1.0, capi.ptr(dC), n)
+    got = capi.to_host(dC)
+    _check(got, ref, k)
+    # the other triangle is untouched, bit for bit
+    other = np.tril(np.ones((n, n), bool), -1) if uplo else np.triu(np.ones((n, n), bool), 1)
+    np.testing.assert_array_equal(got[other], Cm[other])
+
+
+def test_dsyrk_tall_skinny_splitk(hip, oracle):
+    """CholeskyQR2's Gram matrix (cacqr.hpp:14-15): k = m_loc >> n, served by the split-K path; reproducible."""
+    from capital_amd import capi
+    rng = np.random.default_rng(11)
+    k, n = 70001, 256
+    A = _rand(rng, k, n)
+    ref = np.zeros((n, n), order="F")
+    oracle.dsyrk(1, 1, 1.0, A, 0.0, ref)
+    dA = capi.to_device(A)
+    outs = []
+    for _ in range(2):
+        dC = capi.to_device(np.full((n, n), np.nan))
+        hip.call("capi_dsyrk", 1, 1, n, k, 1.0, capi.ptr(dA), k, 0.0, capi.ptr(dC), n)
+        outs.append(capi.to_host(dC))
+    iu = np.triu_indices(n)
+    assert np.abs(outs[0][iu] - ref[iu]).max() <= 1e-14 * k
+    np.testing.assert_array_equal(outs[0][iu], outs[1][iu])
+
+
+@pytest.mark.parametrize("uplo,ta,tb", list(itertools.product((0, 1), (0, 1), (0, 1))))
+def test_dgemmt(hip, oracle, uplo, ta, tb):
+    from capital_amd import capi
+    rng = np.random.default_rng(uplo * 4 + ta * 2 + tb)
+    n, k = 333, 190
+    A = _rand(rng, k, n) if ta else _rand(rng, n, k)
+    B = _rand(rng, n, k) if tb else _rand(rng, k, n)
+    Cm = _rand(rng, n, n)
+    ref = Cm.copy(order="F")
+    oracle.dgemm(ta, tb, 2.0, A, B, 0.5, ref)
+    dC = capi.to_device(Cm)
+    hip.call("capi_dgemmt", uplo, ta, tb, n, k, 2.0, capi.ptr(capi.to_device(A)), A.shape[0], capi.ptr(capi.to_device(B)), B.shape[0], 0.5, capi.ptr(dC), n)
+    got = capi.to_host(dC)
+    tri = np.triu(np.ones((n, n), bool)) if uplo else np.tril(np.ones((n, n), bool))
+    _check(got[tri], ref[tri], k)
+    np.testing.assert_array_equal(got[~tri], Cm[~tri])
+
+
+@pytest.mark.parametrize("side,uplo,trans,diag", list(itertools.product((0, 1), (0, 1), (0, 1), (0, 1))))
+@pytest.mark.parametrize("m,n", [(200, 130), (129, 257), (64, 64)])
+def test_dtrmm(hip, oracle, side, uplo, trans, diag, m, n):
+    from capital_amd import capi
+    rng = np.random.default_rng(side * 8 + uplo * 4 + trans * 2 + diag + m)
+    nt = m if side == 0 else n
+    T = _rand(rng, nt, nt)  # full of junk in the unreferenced triangle on purpose
+    B = _rand(rng, m, n)
+    ref = B.copy(order="F")
+    oracle.dtrmm(side, uplo, trans, diag, -1.5, T, ref)
+    dT, dB, dCm = capi.to_device(T), capi.to_device(B), capi.zeros(m, n)
+    hip.call("capi_dtrmm_oop", side, uplo, trans, diag, m, n, -1.5, capi.ptr(dT), nt, capi.ptr(dB), m, capi.ptr(dCm), m)
+    _check(capi.to_host(dCm), ref, nt)
+    hip.call("capi_dtrmm", side, uplo, trans, diag, m, n, -1.5, capi.ptr(dT), nt, capi.ptr(dB), m)
+    _check(capi.to_host(dB), ref, nt)
+
+
+@pytest.mark.parametrize("side,uplo,trans,diag", list(itertools.product((0, 1), (0, 1), (0, 1), (0, 1))))
+@pytest.mark.parametrize("m,n", [(300, 70), (70, 300), (600, 520)])
+def test_dtrsm(hip, oracle, side, uplo, trans, diag, m, n):
+    from capital_amd import capi
+    rng = np.random.default_rng(side * 8 + uplo * 4 + trans * 2 + diag + m)
+    nt = m if side == 0 else n
+    T = _rand(rng, nt, nt) * 0.1 + np.eye(nt) * 4.0   # well conditioned
+    B = _rand(rng, m, n)
+    ref = B.copy(order="F")
+    oracle.dtrsm(side, uplo, trans, diag, 0.5, T, ref)
+    dT, dB = capi.to_device(T), capi.to_device(B)
+    hip.call("capi_dtrsm", side, uplo, trans, diag, m, n, 0.5, capi.ptr(dT), nt, capi.ptr(dB), m)
+    got = capi.to_host(dB)
+    assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())

@@ -1,0 +1,83 @@
+"""GPU parity: LAPACK-level C-ABI (capi_dpotrf / capi_dtrtri / capi_dpotrf_trtri) against the oracle's
+restatement of LAPACKE_dpotrf/dtrtri (reference src/lapack/interface.hpp:30-58) on the reference's own SPD
+generator (structure.hpp:68-103).  Tolerance 1e-12 relative elementwise (SURVEY.md 8c ii)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [1, 2, 17, 64, 65, 128, 200, 513, 1000, 2048]
+
+
+def _spd(oracle, n):
+    return oracle.distribute_symmetric(n, n, 0, 0, 1, 1)
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_potrf_trtri_fused(hip, oracle, n):
+    from capital_amd import capi
+    A = _spd(oracle, n)
+    Rref = A.copy(order="F")
+    assert oracle.dpotrf(1, Rref) == 0
+    Rref = np.triu(Rref)
+    Xref = Rref.copy(order="F")
+    assert oracle.dtrtri(1, 0, Xref) == 0
+    dA, dX = capi.to_device(A), capi.to_device(np.full((n, n), np.nan))
+    hip.call("capi_reset_info")
+    hip.call("capi_dpotrf_trtri", n, capi.ptr(dA), n, capi.ptr(dX), n)
+    assert hip.info() == 0
+    R, X = capi.to_host(dA), capi.to_host(dX)
+    assert np.abs(R - Rref).max() <= 1e-12 * np.abs(Rref).max()
+    assert np.abs(X - np.triu(Xref)).max() <= 1e-12 * np.abs(Xref).max()
+    assert np.all(np.tril(R, -1) == 0) and np.all(np.tril(X, -1) == 0)     # cyclic_to_local zeroing, util.hpp:131-164
+
+
+@pytest.mark.parametrize("uplo", (0, 1))
+@pytest.mark.parametrize("n", [5, 64, 300, 1500])
+def test_potrf(hip, oracle, uplo, n):
+    from capital_amd import capi
+    A = _spd(oracle, n)
+    ref = A.copy(order="F")
+    assert oracle.dpotrf(uplo, ref) == 0
+    junk = A.copy(order="F")
+    dA = capi.to_device(junk)
+    hip.call("capi_reset_info")
+    hip.call("capi_dpotrf", uplo, n, capi.ptr(dA), n)
+    assert hip.info() == 0
+    got = capi.to_host(dA)
+    tri = np.triu(np.ones((n, n), bool)) if uplo else np.tril(np.ones((n, n), bool))
+    assert np.abs(got[tri] - ref[tri]).max() <= 1e-12 * np.abs(ref[tri]).max()
+    np.testing.assert_array_equal(got[~tri], junk[~tri])     # LAPACK leaves the other triangle alone
+
+
+@pytest.mark.parametrize("uplo,diag", [(1, 0), (1, 1), (0, 0), (0, 1)])
+@pytest.mark.parametrize("n", [3, 64, 129, 700])
+def test_trtri(hip, oracle, uplo, diag, n):
+    from capital_amd import capi
+    rng = np.random.default_rng(n + uplo + diag)
+    T = np.asfortranarray(rng.uniform(-1, 1, (n, n)) * 0.1 + np.eye(n) * 3)
+    ref = T.copy(order="F")
+    assert oracle.dtrtri(uplo, diag, ref) == 0
+    dT = capi.to_device(T)
+    hip.call("capi_dtrtri", uplo, diag, n, capi.ptr(dT), n)
+    got = capi.to_host(dT)
+    tri = np.triu(np.ones((n, n), bool), 1 if diag else 0) if uplo else np.tril(np.ones((n, n), bool), -1 if diag else 0)
+    assert np.abs(got[tri] - ref[tri]).max() <= 1e-12 * max(1.0, np.abs(ref[tri]).max())
+    other = ~(np.triu(np.ones((n, n), bool)) if uplo else np.tril(np.ones((n, n), bool)))
+    np.testing.assert_array_equal(got[other], T[other])
+
+
+def test_potrf_reports_non_spd(hip, oracle):
+    """The reference drops LAPACK's info (lapack/interface.hpp:39); the C-ABI keeps it on the device."""
+    from capital_amd import capi
+    n = 150
+    A = _spd(oracle, n)
+    A[100, 100] = -5.0
+    ref = A.copy(order="F")
+    info_ref = oracle.dpotrf(1, ref)
+    dA, dX = capi.to_device(A), capi.zeros(n, n)
+    hip.call("capi_reset_info")
+    hip.call("capi_dpotrf_trtri", n, capi.ptr(dA), n, capi.ptr(dX), n)
+    assert hip.info() == info_ref == 101
+    hip.call("capi_reset_info")
+    assert hip.info() == 0

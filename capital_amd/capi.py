@@ -28,6 +28,7 @@ _SIGS = {
     "capi_dgemmt": [_int, _int, _int, _i64, _i64, _dbl, _vp, _i64, _vp, _i64, _dbl, _vp, _i64],
     "capi_dtrmm": [_int, _int, _int, _int, _i64, _i64, _dbl, _vp, _i64, _vp, _i64],
     "capi_dtrmm_oop": [_int, _int, _int, _int, _i64, _i64, _dbl, _vp, _i64, _vp, _i64, _vp, _i64],
+    "capi_dtrmm_acc": [_int, _int, _int, _int, _i64, _i64, _dbl, _vp, _i64, _vp, _i64, _dbl, _vp, _i64],
     "capi_dtrsm": [_int, _int, _int, _int, _i64, _i64, _dbl, _vp, _i64, _vp, _i64],
     "capi_dpotrf": [_int, _i64, _vp, _i64],
     "capi_dtrtri": [_int, _int, _i64, _vp, _i64],
@@ -35,7 +36,9 @@ _SIGS = {
     "capi_get_info": [C.POINTER(_int)],
     "capi_reset_info": [],
     "capi_serialize": [_int, _int, _vp, _i64, _i64, _vp, _i64, _i64] + [_i64] * 8,
+    "capi_serialize_shape": [_int, _int, _int, _vp, _i64, _i64, _vp, _i64, _i64] + [_i64] * 8,
     "capi_dlacpy": [_int, _i64, _i64, _vp, _i64, _vp, _i64],
+    "capi_dgeadd": [_int, _i64, _i64, _dbl, _vp, _i64, _dbl, _vp, _i64],
     "capi_dtrizero": [_int, _i64, _vp, _i64],
     "capi_daxpby": [_i64, _dbl, _vp, _vp],
     "capi_remove_triangle": [C.c_char, _vp, _i64, _i64, _i64, _i64, _i64],

@@ -150,13 +150,18 @@ __device__ __forceinline__ d2_t frag_read(const double* __restrict__ L, int row,
 
 __device__ __forceinline__ void tile_of(const GemmArgs& p, int t, int& ti, int& tj) {
   if (p.out_uplo < 0) {
-    const int in_group = GROUP_M * p.tiles_n;
+    // bands of GROUP_M tile-rows (all tile-columns) are dealt to XCDs in order.  A left-side TRMM's work per tile
+    // depends on its tile-ROW, so there the bands run along columns instead: every XCD then gets every row.
+    const bool by_cols = (p.tri_side == CAPI_LEFT);
+    const int nm = by_cols ? p.tiles_n : p.tiles_m, nn = by_cols ? p.tiles_m : p.tiles_n;
+    const int in_group = GROUP_M * nn;
     const int group = t / in_group;
     const int first_m = group * GROUP_M;
-    const int gsz = min(p.tiles_m - first_m, GROUP_M);
+    const int gsz = min(nm - first_m, GROUP_M);
     const int loc = t - group * in_group;
-    ti = first_m + loc % gsz;
-    tj = loc / gsz;
+    const int a = first_m + loc % gsz, b = loc / gsz;
+    ti = by_cols ? b : a;
+    tj = by_cols ? a : b;
   } else {
     // t enumerates pairs (lo <= hi): t = hi*(hi+1)/2 + lo
     int hi = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
@@ -317,9 +322,9 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool allow_spli
   if (p.M <= 0 || p.N <= 0) return CAPI_OK;
   hipStream_t s = h->stream;
   if (p.K <= 0 || p.alpha == 0.0) {
-    if (p.beta == 1.0 && p.tri_side < 0) return CAPI_OK;
+    if (p.beta == 1.0) return CAPI_OK;
     dim3 grid((unsigned)cdiv(p.M, 256), (unsigned)(p.N < 65535 ? p.N : 65535));
-    hipLaunchKernelGGL(scale_kernel, grid, dim3(256), 0, s, p.C, p.ldc, p.M, p.N, p.tri_side < 0 ? p.beta : 0.0, p.out_uplo);
+    hipLaunchKernelGGL(scale_kernel, grid, dim3(256), 0, s, p.C, p.ldc, p.M, p.N, p.beta, p.out_uplo);
     CAPI_HIP_CHECK(h, hipGetLastError());
     return CAPI_OK;
   }
@@ -435,8 +440,8 @@ int capi_dsyrk(capi_handle_t h, int uplo, int trans, int64_t n, int64_t k, doubl
   return capi_dgemmt(h, uplo, trans, trans == CAPI_TRANS ? CAPI_NOTRANS : CAPI_TRANS, n, k, alpha, A, lda, A, lda, beta, C, ldc);
 }
 
-int capi_dtrmm_oop(capi_handle_t h, int side, int uplo, int trans, int diag, int64_t m, int64_t n, double alpha,
-                   const double* T, int64_t ldt, const double* B, int64_t ldb, double* C, int64_t ldc) {
+static int trmm_launch(capi_handle_t h, int side, int uplo, int trans, int diag, int64_t m, int64_t n, double alpha,
+                       const double* T, int64_t ldt, const double* B, int64_t ldb, double beta, double* C, int64_t ldc) {
   CAPI_REQUIRE(h, h, "null handle");
   CAPI_REQUIRE(h, ok01(side) && ok01(uplo) && ok01(trans) && ok01(diag), "enum code");
   CAPI_REQUIRE(h, m >= 0 && n >= 0 && m < (1LL << 31) && n < (1LL << 31), "dims");
@@ -445,7 +450,7 @@ int capi_dtrmm_oop(capi_handle_t h, int side, int uplo, int trans, int diag, int
   CAPI_REQUIRE(h, T && B && C && ldt >= nt && ldb >= m && ldc >= m, "operands");
   CAPI_REQUIRE(h, (const double*)C != B, "out-of-place trmm: C aliases B");
   GemmArgs p{};
-  p.C = C; p.ldc = ldc; p.M = (int)m; p.N = (int)n; p.K = (int)nt; p.alpha = alpha; p.beta = 0.0;
+  p.C = C; p.ldc = ldc; p.M = (int)m; p.N = (int)n; p.K = (int)nt; p.alpha = alpha; p.beta = beta;
   p.out_uplo = -1;
   p.tri_side = side;
   p.tri_eff_upper = ((uplo == CAPI_UPPER) != (trans == CAPI_TRANS));
@@ -457,6 +462,16 @@ int capi_dtrmm_oop(capi_handle_t h, int side, int uplo, int trans, int diag, int
     p.A = B; p.lda = ldb; p.B = T; p.ldb = ldt;
     return launch_gemm(h, false, trans == CAPI_NOTRANS, p, false);
   }
+}
+
+int capi_dtrmm_oop(capi_handle_t h, int side, int uplo, int trans, int diag, int64_t m, int64_t n, double alpha,
+                   const double* T, int64_t ldt, const double* B, int64_t ldb, double* C, int64_t ldc) {
+  return trmm_launch(h, side, uplo, trans, diag, m, n, alpha, T, ldt, B, ldb, 0.0, C, ldc);
+}
+
+int capi_dtrmm_acc(capi_handle_t h, int side, int uplo, int trans, int diag, int64_t m, int64_t n, double alpha,
+                   const double* T, int64_t ldt, const double* B, int64_t ldb, double beta, double* C, int64_t ldc) {
+  return trmm_launch(h, side, uplo, trans, diag, m, n, alpha, T, ldt, B, ldb, beta, C, ldc);
 }
 
 int capi_dtrmm(capi_handle_t h, int side, int uplo, int trans, int diag, int64_t m, int64_t n, double alpha,

@@ -19,12 +19,12 @@ __device__ __host__ inline int64_t st_offset(int st, int64_t x, int64_t y, int64
   return x * dimY + y - (x * (x + 1) / 2);
 }
 
-__global__ void serialize_kernel(int ss, int ds, const double* __restrict__ src, int64_t sdimY, double* __restrict__ dst,
+__global__ void serialize_kernel(int shape, int ss, int ds, const double* __restrict__ src, int64_t sdimY, double* __restrict__ dst,
                                  int64_t ddimY, int64_t ssx, int64_t ssy, int64_t dsx, int64_t dsy, int64_t rangeX,
                                  int64_t rangeY) {
   const int64_t y = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   for (int64_t i = blockIdx.y; i < rangeX; i += gridDim.y) {
-  const bool lower = (ss == CAPI_LOWERTRI || ds == CAPI_LOWERTRI), upper = (ss == CAPI_UPPERTRI || ds == CAPI_UPPERTRI);
+  const bool lower = shape == CAPI_LOWERTRI, upper = shape == CAPI_UPPERTRI;
   int64_t so, d_o, cnt;
   if (lower) {
     so = st_offset(ss, ssx + i, ssy + i, sdimY);
@@ -51,6 +51,19 @@ __global__ void lacpy_kernel(int part, int64_t m, int64_t n, const double* __res
     if (part == 1 && i > j) continue;
     if (part == 2 && i < j) continue;
     B[i + j * ldb] = A[i + j * lda];
+  }
+}
+
+// Y(part) <- alpha*X + beta*Y on an m x n block (summa.hpp:33,153 generalised to strided blocks)
+__global__ void geadd_kernel(int part, int64_t m, int64_t n, double alpha, const double* __restrict__ X, int64_t ldx, double beta,
+                             double* __restrict__ Y, int64_t ldy) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  for (int64_t j = blockIdx.y; j < n; j += gridDim.y) {
+    if (part == 1 && i > j) continue;
+    if (part == 2 && i < j) continue;
+    const double x = alpha == 0.0 ? 0.0 : alpha * X[i + j * ldx];
+    Y[i + j * ldy] = beta == 0.0 ? x : x + beta * Y[i + j * ldy];
   }
 }
 
@@ -192,20 +205,28 @@ inline dim3 grid2(int64_t rows, int64_t cols) { return dim3((unsigned)cdiv(rows,
 
 extern "C" {
 
-int capi_serialize(capi_handle_t h, int ss, int ds, const double* src, int64_t sdimX, int64_t sdimY, double* dst, int64_t ddimX,
-                   int64_t ddimY, int64_t ssx, int64_t sex, int64_t ssy, int64_t sey, int64_t dsx, int64_t dex, int64_t dsy,
-                   int64_t dey) {
+int capi_serialize_shape(capi_handle_t h, int shape, int ss, int ds, const double* src, int64_t sdimX, int64_t sdimY, double* dst,
+                         int64_t ddimX, int64_t ddimY, int64_t ssx, int64_t sex, int64_t ssy, int64_t sey, int64_t dsx, int64_t dex,
+                         int64_t dsy, int64_t dey) {
   CAPI_REQUIRE(h, h, "null handle");
-  CAPI_REQUIRE(h, ss >= 0 && ss <= 2 && ds >= 0 && ds <= 2, "structure code");
+  CAPI_REQUIRE(h, ss >= 0 && ss <= 2 && ds >= 0 && ds <= 2 && shape >= 0 && shape <= 2, "structure code");
   CAPI_REQUIRE(h, (sex - ssx) == (dex - dsx) && (sey - ssy) == (dey - dsy), "source and destination ranges differ");  // serialize.hpp:19
   (void)sdimX; (void)ddimX;
   const int64_t rangeX = sex - ssx, rangeY = sey - ssy;
   if (rangeX <= 0 || rangeY <= 0) return CAPI_OK;
   CAPI_REQUIRE(h, src && dst, "null matrix");
-  hipLaunchKernelGGL(serialize_kernel, grid2(rangeY, rangeX), dim3(256), 0, h->stream, ss, ds, src, sdimY, dst, ddimY, ssx, ssy, dsx,
-                     dsy, rangeX, rangeY);
+  hipLaunchKernelGGL(serialize_kernel, grid2(rangeY, rangeX), dim3(256), 0, h->stream, shape, ss, ds, src, sdimY, dst, ddimY, ssx, ssy,
+                     dsx, dsy, rangeX, rangeY);
   CAPI_HIP_CHECK(h, hipGetLastError());
   return CAPI_OK;
+}
+
+int capi_serialize(capi_handle_t h, int ss, int ds, const double* src, int64_t sdimX, int64_t sdimY, double* dst, int64_t ddimX,
+                   int64_t ddimY, int64_t ssx, int64_t sex, int64_t ssy, int64_t sey, int64_t dsx, int64_t dex, int64_t dsy,
+                   int64_t dey) {
+  // copy shape follows the structures, as the reference's seven specialisations do (serialize.hpp:12-150)
+  const int shape = (ss == CAPI_LOWERTRI || ds == CAPI_LOWERTRI) ? CAPI_LOWERTRI : ((ss == CAPI_UPPERTRI || ds == CAPI_UPPERTRI) ? CAPI_UPPERTRI : CAPI_RECT);
+  return capi_serialize_shape(h, shape, ss, ds, src, sdimX, sdimY, dst, ddimX, ddimY, ssx, sex, ssy, sey, dsx, dex, dsy, dey);
 }
 
 int capi_dlacpy(capi_handle_t h, int part, int64_t m, int64_t n, const double* A, int64_t lda, double* B, int64_t ldb) {
@@ -221,6 +242,17 @@ int capi_dlacpy(capi_handle_t h, int part, int64_t m, int64_t n, const double* A
   const int64_t gy = cdiv(n, 8);
   CAPI_REQUIRE(h, gy <= 65535, "n too large");
   hipLaunchKernelGGL(lacpy_kernel, dim3((unsigned)cdiv(m, 256), (unsigned)gy), dim3(256), 0, h->stream, part, m, n, A, lda, B, ldb);
+  CAPI_HIP_CHECK(h, hipGetLastError());
+  return CAPI_OK;
+}
+
+int capi_dgeadd(capi_handle_t h, int part, int64_t m, int64_t n, double alpha, const double* X, int64_t ldx, double beta, double* Y,
+                int64_t ldy) {
+  CAPI_REQUIRE(h, h, "null handle");
+  CAPI_REQUIRE(h, part >= 0 && part <= 2 && m >= 0 && n >= 0, "args");
+  if (m == 0 || n == 0) return CAPI_OK;
+  CAPI_REQUIRE(h, X && Y && ldx >= m && ldy >= m, "operands");
+  hipLaunchKernelGGL(geadd_kernel, grid2(m, n), dim3(256), 0, h->stream, part, m, n, alpha, X, ldx, beta, Y, ldy);
   CAPI_HIP_CHECK(h, hipGetLastError());
   return CAPI_OK;
 }

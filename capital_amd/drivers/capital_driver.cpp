@@ -1,0 +1,170 @@
+// capital_driver.cpp -- C-ABI over the host-side C++ layer (capital_amd/src): what bench.py, the parity tests and a
+// foreign-language caller bind.  It plays the part of the reference's bench mains (bench/cholesky/cholinv.cpp:8-71,
+// bench/qr/cacqr.cpp:8-77) split into create / generate / factor / validate steps so that a launcher can time factor()
+// alone.  Policy templates are instantiated for every combination the reference exposes.
+#include <memory>
+
+#include "../src/alg/cholesky/cholinv/cholinv.h"
+#include "../src/alg/qr/cacqr/cacqr.h"
+#include "../test/cholesky/validate.h"
+#include "../test/qr/validate.h"
+
+namespace {
+
+std::string g_err;
+template <typename F>
+int guarded(F&& f) {
+  try {
+    f();
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+
+using T = double;
+using U = int64_t;
+using MatrixType = matrix<T, U, rect>;
+
+struct cholinv_problem {
+  virtual ~cholinv_problem() {}
+  virtual void generate() = 0;
+  virtual void set_A(const double* host) = 0;
+  virtual void factor() = 0;
+  virtual double residual() = 0;
+  virtual void get(int which, double* host) = 0;
+  virtual void dims(int64_t* nloc, int* x, int* y, int* z, int* d, int* c) = 0;
+  virtual void stats(int64_t* bc, int64_t* levels, int64_t* bcdim) = 0;
+};
+
+template <class Alg>
+struct cholinv_impl : cholinv_problem {
+  topo::square grid;
+  MatrixType A;
+  typename Alg::template info<T, U> pack;
+  cholinv_impl(int64_t n, int c, int layout, int chunks, int complete_inv, int split, int bc_mult)
+      : grid(capital::world(), (size_t)c, (size_t)layout, (size_t)chunks), A(n, n, grid.d, grid.d), pack(complete_inv, split, bc_mult, 'U') {}
+  void generate() override { A.distribute_symmetric(grid.x, grid.y, grid.d, grid.d, grid.rank / grid.c, true); }   // bench/cholesky/cholinv.cpp:40
+  void set_A(const double* host) override { A.from_host(host); }
+  void factor() override { Alg::factor(A, pack, grid); }
+  double residual() override { return cholesky::validate<Alg>::residual(A, pack, grid); }
+  void get(int which, double* host) override {
+    if (which == 0) { auto v = A.to_host(); std::memcpy(host, v.data(), sizeof(double) * v.size()); return; }
+    auto M = which == 1 ? Alg::construct_R(pack, grid) : Alg::construct_Rinv(pack, grid);
+    auto v = M.to_host();
+    std::memcpy(host, v.data(), sizeof(double) * v.size());
+  }
+  void dims(int64_t* nloc, int* x, int* y, int* z, int* d, int* c) override {
+    *nloc = A.num_rows_local(); *x = (int)grid.x; *y = (int)grid.y; *z = (int)grid.z; *d = (int)grid.d; *c = (int)grid.c;
+  }
+  void stats(int64_t* bc, int64_t* levels, int64_t* bcdim) override { *bc = pack.num_base_cases; *levels = pack.num_levels; *bcdim = pack.bcDimension; }
+};
+
+template <class SP>
+cholinv_problem* make_cholinv(int bc_policy, int64_t n, int c, int layout, int chunks, int ci, int split, int bcm) {
+  namespace P = cholesky::policy::cholinv;
+  switch (bc_policy) {
+    case 0: return new cholinv_impl<cholesky::cholinv<SP, P::SaveIntermediates, P::ReplicateCommComp>>(n, c, layout, chunks, ci, split, bcm);
+    case 1: return new cholinv_impl<cholesky::cholinv<SP, P::SaveIntermediates, P::ReplicateComp>>(n, c, layout, chunks, ci, split, bcm);
+    case 2: return new cholinv_impl<cholesky::cholinv<SP, P::SaveIntermediates, P::NoReplication>>(n, c, layout, chunks, ci, split, bcm);
+    case 3: return new cholinv_impl<cholesky::cholinv<SP, P::SaveIntermediates, P::NoReplicationOverlap>>(n, c, layout, chunks, ci, split, bcm);
+  }
+  throw std::invalid_argument("base-case policy id must be 0..3 (policy.h get_id)");
+}
+
+struct cacqr_problem {
+  virtual ~cacqr_problem() {}
+  virtual void generate() = 0;
+  virtual void set_A(const double* host) = 0;
+  virtual void factor() = 0;
+  virtual double residual() = 0;
+  virtual double orthogonality() = 0;
+  virtual void get(int which, double* host) = 0;
+  virtual void dims(int64_t* mloc, int64_t* n) = 0;
+};
+
+template <class Alg>
+struct cacqr_impl : cacqr_problem {
+  using CI = cholesky::cholinv<cholesky::policy::cholinv::Serialize, cholesky::policy::cholinv::SaveIntermediates, cholesky::policy::cholinv::NoReplication>;
+  topo::rect grid;
+  MatrixType A;
+  typename Alg::template info<T, U, CI> pack;
+  cacqr_impl(int64_t m, int64_t n, int c, int variant, int layout, int chunks, int ci, int split, int bcm)
+      : grid(capital::world(), (size_t)c, (size_t)layout, (size_t)chunks), A(n, m, grid.c, grid.d),
+        pack((size_t)variant, typename CI::template info<T, U>(ci, split, bcm, 'U')) {}
+  void generate() override { A.distribute_random(grid.x, grid.y, grid.c, grid.d, grid.rank / grid.c); }             // bench/qr/cacqr.cpp:34
+  void set_A(const double* host) override { A.from_host(host); }
+  void factor() override { Alg::factor(A, pack, grid); }
+  double residual() override { return qr::validate<Alg>::residual(A, pack, grid); }
+  double orthogonality() override { return qr::validate<Alg>::orthogonality(A, pack, grid); }
+  void get(int which, double* host) override {
+    if (which == 0) { auto v = A.to_host(); std::memcpy(host, v.data(), sizeof(double) * v.size()); return; }
+    if (which == 1) { auto v = Alg::construct_Q(pack, grid).to_host(); std::memcpy(host, v.data(), sizeof(double) * v.size()); return; }
+    auto v = Alg::construct_R(pack, grid).to_host();
+    std::memcpy(host, v.data(), sizeof(double) * v.size());
+  }
+  void dims(int64_t* mloc, int64_t* n) override { *mloc = A.num_rows_local(); *n = A.num_columns_local(); }
+};
+
+}  // namespace
+
+extern "C" {
+
+const char* capital_drv_last_error(void) { return g_err.c_str(); }
+
+// stream != NULL: run on the caller's HIP stream (e.g. torch's current stream); uid: 128-byte RCCL id when size > 1
+int capital_drv_init(int device, int rank, int size, const void* uid, void* stream) {
+  return guarded([&] {
+    if (stream) {
+      capi_handle_t h;
+      if (capi_create_on_stream(&h, device, stream) != CAPI_OK) throw std::runtime_error("capi_create_on_stream failed");
+      capital::ctx().owns_handle = true;
+      capital::ctx().device = device;
+      capital::init_with_handle(h, rank, size, uid);
+    } else {
+      capital::init(device, rank, size, uid);
+    }
+  });
+}
+int capital_drv_finalize(void) { return guarded([] { capital::finalize(); }); }
+int capital_drv_sync(void) { return guarded([] { capital::sync(); }); }
+void* capital_drv_handle(void) { return capital::ctx().handle; }
+
+void* capital_cholinv_create(int64_t n, int c, int layout, int num_chunks, int complete_inv, int split, int bc_mult, int serialize_, int bc_policy) {
+  cholinv_problem* p = nullptr;
+  int rc = guarded([&] {
+    namespace P = cholesky::policy::cholinv;
+    p = serialize_ ? make_cholinv<P::Serialize>(bc_policy, n, c, layout, num_chunks, complete_inv, split, bc_mult)
+                   : make_cholinv<P::NoSerialize>(bc_policy, n, c, layout, num_chunks, complete_inv, split, bc_mult);
+  });
+  return rc ? nullptr : p;
+}
+int capital_cholinv_generate(void* p) { return guarded([&] { ((cholinv_problem*)p)->generate(); }); }
+int capital_cholinv_set_A(void* p, const double* host) { return guarded([&] { ((cholinv_problem*)p)->set_A(host); }); }
+int capital_cholinv_factor(void* p) { return guarded([&] { ((cholinv_problem*)p)->factor(); }); }
+int capital_cholinv_residual(void* p, double* out) { return guarded([&] { *out = ((cholinv_problem*)p)->residual(); }); }
+int capital_cholinv_get(void* p, int which, double* host) { return guarded([&] { ((cholinv_problem*)p)->get(which, host); }); }
+int capital_cholinv_dims(void* p, int64_t* nloc, int* x, int* y, int* z, int* d, int* c) { return guarded([&] { ((cholinv_problem*)p)->dims(nloc, x, y, z, d, c); }); }
+int capital_cholinv_stats(void* p, int64_t* bc, int64_t* levels, int64_t* bcdim) { return guarded([&] { ((cholinv_problem*)p)->stats(bc, levels, bcdim); }); }
+int capital_cholinv_destroy(void* p) { return guarded([&] { capital::sync(); delete (cholinv_problem*)p; }); }
+
+void* capital_cacqr_create(int64_t m, int64_t n, int c, int variant, int layout, int num_chunks, int complete_inv, int split, int bc_mult, int serialize_) {
+  cacqr_problem* p = nullptr;
+  int rc = guarded([&] {
+    namespace P = qr::policy::cacqr;
+    if (serialize_) p = new cacqr_impl<qr::cacqr<P::Serialize, P::SaveIntermediates>>(m, n, c, variant, layout, num_chunks, complete_inv, split, bc_mult);
+    else p = new cacqr_impl<qr::cacqr<P::NoSerialize, P::SaveIntermediates>>(m, n, c, variant, layout, num_chunks, complete_inv, split, bc_mult);
+  });
+  return rc ? nullptr : p;
+}
+int capital_cacqr_generate(void* p) { return guarded([&] { ((cacqr_problem*)p)->generate(); }); }
+int capital_cacqr_set_A(void* p, const double* host) { return guarded([&] { ((cacqr_problem*)p)->set_A(host); }); }
+int capital_cacqr_factor(void* p) { return guarded([&] { ((cacqr_problem*)p)->factor(); }); }
+int capital_cacqr_residual(void* p, double* out) { return guarded([&] { *out = ((cacqr_problem*)p)->residual(); }); }
+int capital_cacqr_orthogonality(void* p, double* out) { return guarded([&] { *out = ((cacqr_problem*)p)->orthogonality(); }); }
+int capital_cacqr_get(void* p, int which, double* host) { return guarded([&] { ((cacqr_problem*)p)->get(which, host); }); }
+int capital_cacqr_dims(void* p, int64_t* mloc, int64_t* n) { return guarded([&] { ((cacqr_problem*)p)->dims(mloc, n); }); }
+int capital_cacqr_destroy(void* p) { return guarded([&] { capital::sync(); delete (cacqr_problem*)p; }); }
+
+}  // extern "C"

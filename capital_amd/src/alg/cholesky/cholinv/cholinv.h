@@ -1,0 +1,249 @@
+// alg/cholesky/cholinv/cholinv.h -- recursive Cholesky with triangular inverse on MI355X
+// (reference src/alg/cholesky/cholinv/cholinv.h:11-75, cholinv.hpp:6-183).
+//
+// Same call surface: cholinv<SerializePolicy,IntermediatesPolicy,BaseCasePolicy>::factor(A, args, topo),
+// construct_R / construct_Rinv, and the info<T,U> pack (complete_inv, split, bc_mult_dim, dir; R, Rinv).
+// Same schedule per recursion level (cholinv.hpp:107-155):
+//   1. recurse on the leading block                         -> R11, R11^-1
+//   2. CI::trsm   R12 = R11^-T * A12                        (trmm Left/Upper/Trans SUMMA)
+//   3. CI::tmu    A22 <- A22 - R12^T R12                    (triangular-output SUMMA)
+//   4. recurse on the trailing block                        -> R22, R22^-1
+//   5. CI::tmu    R^-1_12 = -R11^-1 R12 R22^-1              (two trmm SUMMAs; skipped at the top level when !complete_inv)
+// What is different underneath: blocks are views into the device-resident R / R^-1 (no serialize copies into per-level
+// tables), every multiply runs on the fp64 MFMA tile kernel, step 3 computes only the upper triangle, and the base case
+// is one fused potrf+trtri launch sequence on the aggregated block.
+#ifndef CAPITAL_CHOLESKY_CHOLINV_H_
+#define CAPITAL_CHOLESKY_CHOLINV_H_
+
+#include "./../../alg.h"
+#include "./../../matmult/summa/summa.h"
+#include "./policy.h"
+
+namespace cholesky {
+
+template <class SerializePolicy = policy::cholinv::Serialize, class IntermediatesPolicy = policy::cholinv::SaveIntermediates,
+          class BaseCasePolicy = policy::cholinv::NoReplication>
+class cholinv : public SerializePolicy, public IntermediatesPolicy, public BaseCasePolicy {
+public:
+  using SP = SerializePolicy;
+  using IP = IntermediatesPolicy;
+  using BP = BaseCasePolicy;
+
+  template <typename ScalarT, typename DimensionT>
+  class info {
+  public:
+    using ScalarType = ScalarT;
+    using DimensionType = DimensionT;
+    using alg_type = cholinv<SerializePolicy, IntermediatesPolicy, BaseCasePolicy>;
+    using SP = SerializePolicy;
+    using IP = IntermediatesPolicy;
+    using BP = BaseCasePolicy;
+    info(const info& p) : complete_inv(p.complete_inv), split(p.split), bc_mult_dim(p.bc_mult_dim), dir(p.dir) {}
+    info(info&& p) : complete_inv(p.complete_inv), split(p.split), bc_mult_dim(p.bc_mult_dim), dir(p.dir) {}
+    info(DimensionType complete_inv, DimensionType split, DimensionType bc_mult_dim, char dir)
+        : complete_inv(complete_inv), split(split), bc_mult_dim(bc_mult_dim), dir(dir) {}
+    // user input (cholinv.h:50-53)
+    const DimensionType complete_inv, split, bc_mult_dim;
+    const char dir;
+    // factors (cholinv.h:55-56)
+    matrix<ScalarType, DimensionType, typename SerializePolicy::structure> R, Rinv;
+    // full-storage working images when the returned structure is packed
+    matrix<ScalarType, DimensionType, rect> Rfull, Rinvfull;
+    matmult::arena work;
+    DimensionType localDimension = 0, globalDimension = 0, trueLocalDimension = 0, trueGlobalDimension = 0, bcDimension = 0;
+    // bookkeeping exposed for tests / benches
+    int64_t num_base_cases = 0, num_levels = 0;
+  };
+
+  template <typename MatrixType, typename ArgType, typename CommType>
+  static void factor(const MatrixType& A, ArgType& args, CommType&& CommInfo) {
+    CRITTER_START(CI::factor);
+    using U = typename ArgType::DimensionType;
+    static_assert(std::is_same<typename MatrixType::StructureType, rect>::value, "cholinv::factor takes a rect-structured input block");
+    if (!(args.split > 0) || args.dir != 'U') throw std::invalid_argument("cholinv: split > 0 and dir == 'U' required (cholinv.hpp:9)");
+    if (CommInfo.d > 1 && CommInfo.d % CommInfo.c) throw std::invalid_argument("cholinv: c must divide d (or d == 1)");
+    const U localDimension = A.num_rows_local(), globalDimension = A.num_rows_global();
+    args.R._register_(A.num_columns_global(), A.num_rows_global(), CommInfo.d, CommInfo.d);
+    args.Rinv._register_(A.num_columns_global(), A.num_rows_global(), CommInfo.d, CommInfo.d);
+    constexpr bool packed = !std::is_same<typename SP::structure, rect>::value;
+    if (packed) {
+      args.Rfull._register_(A.num_columns_global(), A.num_rows_global(), CommInfo.d, CommInfo.d);
+      args.Rinvfull._register_(A.num_columns_global(), A.num_rows_global(), CommInfo.d, CommInfo.d);
+    }
+    double* R = packed ? args.Rfull.data() : (double*)args.R.data();
+    double* Ri = packed ? args.Rinvfull.data() : (double*)args.Rinv.data();
+    const U ld = localDimension;
+    // cholinv.hpp:13: the upper triangle of the input becomes the working R; the rest of R and all of R^-1 are zero
+    capital::dev_zero(R, ld * ld);
+    capital::dev_zero(Ri, ld * ld);
+    CAPITAL_CHECK(capi_dlacpy(capital::handle(), 1, ld, ld, A.data(), ld, R, ld));
+
+    // base-case size rule, cholinv.hpp:15-18
+    U bcDimLocal = (U)(CommInfo.c * CommInfo.d);
+    U bcMult = args.bc_mult_dim;
+    if (bcMult < 0) { bcMult = -bcMult; for (U i = 0; i < bcMult; ++i) bcDimLocal *= 2; } else { for (U i = 0; i < bcMult; ++i) bcDimLocal /= 2; }
+    bcDimLocal = std::max<U>(1, bcDimLocal);
+    bcDimLocal = std::min<U>(localDimension, bcDimLocal);
+    bcDimLocal = localDimension / bcDimLocal;
+    args.localDimension = args.trueLocalDimension = localDimension;
+    args.globalDimension = args.trueGlobalDimension = globalDimension;
+    args.bcDimension = (U)CommInfo.d * bcDimLocal;
+    args.num_base_cases = args.num_levels = 0;
+
+    // the reference's simulate() (cholinv.hpp:50-83) pre-allocates every level's tables; here ONE arena covers the
+    // deepest concurrent need: panels + partial sums of the top level, or the aggregated base case
+    const bool single = (CommInfo.d == 1 && CommInfo.c == 1);
+    const U h = localDimension - (localDimension >> args.split);
+    const U agg = args.bcDimension;
+    int64_t need = single ? (int64_t)h * h + 64 : (int64_t)8 * h * h + 4 * (int64_t)agg * agg + 1024;
+    args.work.reserve(need);
+
+    invoke(args, CommInfo, R, Ri, ld, (U)0, localDimension, globalDimension);
+
+    if (packed) {
+      serialize<uppertri, uppertri>::invoke(args.Rfull, args.R, 0, ld, 0, ld, 0, ld, 0, ld);
+      serialize<uppertri, uppertri>::invoke(args.Rinvfull, args.Rinv, 0, ld, 0, ld, 0, ld, 0, ld);
+    }
+    if (!IP::keep_arena) { capital::sync(); args.work = matmult::arena(); }
+    CRITTER_STOP(CI::factor);
+  }
+
+  // full local images of the factors (cholinv.hpp:30-46)
+  template <typename ArgType, typename CommType>
+  static matrix<typename ArgType::ScalarType, typename ArgType::DimensionType, rect> construct_R(ArgType& args, CommType&& CommInfo) {
+    return construct(args.R, CommInfo);
+  }
+  template <typename ArgType, typename CommType>
+  static matrix<typename ArgType::ScalarType, typename ArgType::DimensionType, rect> construct_Rinv(ArgType& args, CommType&& CommInfo) {
+    return construct(args.Rinv, CommInfo);
+  }
+
+private:
+  template <typename M, typename CommType>
+  static matrix<typename M::ScalarType, typename M::DimensionType, rect> construct(M& src, CommType&& CommInfo) {
+    const auto ld = src.num_rows_local();
+    matrix<typename M::ScalarType, typename M::DimensionType, rect> ret(src.num_columns_global(), src.num_rows_global(), CommInfo.d, CommInfo.d);
+    serialize<typename SP::structure, rect>::invoke(src, ret, 0, ld, 0, ld, 0, ld, 0, ld);
+    return ret;
+  }
+
+  template <typename ArgType, typename CommType, typename U>
+  static void invoke(ArgType& args, CommType&& t, double* R, double* Ri, U ld, U start, U localDim, U globalDim) {
+    using matmult::view;
+    capi_handle_t h = capital::handle();
+    const U split1 = localDim >> args.split;
+    if (((localDim * (U)t.d) <= args.bcDimension) || (split1 < args.split)) {     // cholinv.hpp:93
+      CRITTER_START(CI::factor_diag);
+      base_case(args, t, R, Ri, ld, start, localDim);
+      CRITTER_STOP(CI::factor_diag);
+      return;
+    }
+    ++args.num_levels;
+    const U split2 = localDim - split1;
+    const bool single = (t.d == 1 && t.c == 1);
+    matmult::arena& ws = args.work;
+    // local blocks (column-major, column index first in the reference's (X,Y) convention)
+    view R11i{Ri + start + start * ld, ld, split1, split1};
+    view A12{R + start + (start + split1) * ld, ld, split1, split2};
+    view A22{R + (start + split1) + (start + split1) * ld, ld, split2, split2};
+    view R22i{Ri + (start + split1) + (start + split1) * ld, ld, split2, split2};
+    view I12{Ri + start + (start + split1) * ld, ld, split1, split2};
+
+    invoke(args, t, R, Ri, ld, start, split1, globalDim >> 1);                          // 1
+
+    CRITTER_START(CI::trsm);                                                            // 2
+    {
+      const int64_t mark = ws.top;
+      view W{ws.take((int64_t)split1 * split2), split1, split1, split2};
+      if (single) {
+        CAPITAL_CHECK(capi_dtrmm_oop(h, CAPI_LEFT, CAPI_UPPER, CAPI_TRANS, CAPI_NONUNIT, split1, split2, 1.0, R11i.p, ld, A12.p, ld, W.p, W.ld));
+      } else {
+        // partner-exchanged copy of R11^-1 (cholinv.hpp:116-117)
+        view Tx{ws.take((int64_t)split1 * split1), split1, split1, split1};
+        CAPITAL_CHECK(capi_dlacpy(h, 0, split1, split1, R11i.p, ld, Tx.p, Tx.ld));
+        util::transpose_raw(Tx.p, Tx.count(), ws.take(Tx.count()), t);
+        matmult::summa::trmm(t, CAPI_LEFT, CAPI_UPPER, CAPI_TRANS, CAPI_NONUNIT, 1.0, Tx, A12, W, ws);
+      }
+      CAPITAL_CHECK(capi_dlacpy(h, 0, split1, split2, W.p, W.ld, A12.p, ld));            // R12 into R (cholinv.hpp:122)
+      CRITTER_STOP(CI::trsm);
+
+      CRITTER_START(CI::tmu);                                                           // 3
+      if (single) {
+        CAPITAL_CHECK(capi_dgemmt(h, CAPI_UPPER, CAPI_TRANS, CAPI_NOTRANS, split2, split1, -1.0, W.p, W.ld, W.p, W.ld, 1.0, A22.p, ld));
+      } else {
+        view Wx{ws.take(W.count()), split1, split1, split2};
+        capital::dev_copy(Wx.p, W.p, W.count());
+        util::transpose_raw(Wx.p, Wx.count(), ws.take(Wx.count()), t);
+        matmult::summa::syrk(t, CAPI_UPPER, CAPI_TRANS, -1.0, W, Wx, 1.0, A22, ws);
+      }
+      ws.top = mark;
+      CRITTER_STOP(CI::tmu);
+    }
+
+    invoke(args, t, R, Ri, ld, start + split1, split2, split2 * (U)t.d);                // 4
+
+    CRITTER_START(CI::tmu);                                                             // 5
+    if (!(!args.complete_inv && (globalDim == args.trueGlobalDimension))) {
+      const int64_t mark = ws.top;
+      view W2{ws.take((int64_t)split1 * split2), split1, split1, split2};
+      matmult::summa::trmm(t, CAPI_LEFT, CAPI_UPPER, CAPI_NOTRANS, CAPI_NONUNIT, 1.0, R11i, A12, W2, ws);
+      if (single) {
+        matmult::summa::trmm(t, CAPI_RIGHT, CAPI_UPPER, CAPI_NOTRANS, CAPI_NONUNIT, -1.0, R22i, W2, I12, ws);
+      } else {
+        view W3{ws.take(W2.count()), split1, split1, split2};
+        matmult::summa::trmm(t, CAPI_RIGHT, CAPI_UPPER, CAPI_NOTRANS, CAPI_NONUNIT, -1.0, R22i, W2, W3, ws);
+        CAPITAL_CHECK(capi_dlacpy(h, 0, split1, split2, W3.p, W3.ld, I12.p, ld));
+      }
+      ws.top = mark;
+    }
+    CRITTER_STOP(CI::tmu);
+  }
+
+  // cholinv.hpp:170-183 + policy.h:160-514
+  template <typename ArgType, typename CommType, typename U>
+  static void base_case(ArgType& args, CommType&& t, double* R, double* Ri, U ld, U start, U localDim) {
+    capi_handle_t h = capital::handle();
+    ++args.num_base_cases;
+    double* Rb = R + start + start * ld;
+    double* Ib = Ri + start + start * ld;
+    if (t.d == 1) {
+      // the whole diagonal block is local: factor and invert it in place (every layer holds the same block)
+      CAPITAL_CHECK(capi_dpotrf_trtri(h, localDim, Rb, ld, Ib, ld));
+      return;
+    }
+    const int64_t d = (int64_t)t.d, agg = (int64_t)localDim * d, piece = (int64_t)localDim * localDim;
+    // `span`: the aggregate minus the global padding when this is the last block (policy.h:196)
+    const int64_t span = ((start + localDim) != args.trueLocalDimension) ? agg : agg - (args.trueLocalDimension * d - args.trueGlobalDimension);
+    matmult::arena& ws = args.work;
+    const int64_t mark = ws.top;
+    double* mine = ws.take(piece);
+    double* blocked = ws.take(piece * d * d);
+    double* cyc = ws.take(agg * agg);
+    double* cyci = ws.take(agg * agg);
+    const bool worker = BP::every_layer || t.z == 0;
+    if (worker) {
+      CAPITAL_CHECK(capi_dlacpy(h, 0, localDim, localDim, Rb, ld, mine, localDim));
+      // C5 (Allgather over slice); the gather-to-root strategies (C6) are served by the same collective: on xGMI an
+      // all-gather of bc_loc^2 doubles costs the same single step as a gather and saves the scatter on the way back
+      CAPITAL_CHECK(capi_allgather(t.slice, mine, blocked, piece));
+      util::block_to_cyclic_rect(blocked, cyc, localDim, localDim, d);
+      capital::dev_zero(cyci, agg * agg);
+      CAPITAL_CHECK(capi_dpotrf_trtri(h, span, cyc, agg, cyci, agg));
+    }
+    if (!BP::every_layer) {                                                              // C7
+      CAPITAL_CHECK(capi_bcast(t.depth, cyc, agg * agg, 0));
+      CAPITAL_CHECK(capi_bcast(t.depth, cyci, agg * agg, 0));
+    }
+    // util::cyclic_to_local (util.hpp:131-164): this rank's element-cyclic piece of both factors
+    const int64_t me = (int64_t)t.x + d * (int64_t)t.y;
+    util::cyclic_to_block_rect(blocked, cyc, localDim, localDim, d);
+    CAPITAL_CHECK(capi_dlacpy(h, 0, localDim, localDim, blocked + me * piece, localDim, Rb, ld));
+    util::cyclic_to_block_rect(blocked, cyci, localDim, localDim, d);
+    CAPITAL_CHECK(capi_dlacpy(h, 0, localDim, localDim, blocked + me * piece, localDim, Ib, ld));
+    ws.top = mark;
+  }
+};
+
+}  // namespace cholesky
+
+#endif  // CAPITAL_CHOLESKY_CHOLINV_H_

@@ -1,0 +1,266 @@
+// alg/matmult/summa/summa.h -- 3-D SUMMA on the GPUs of one node (reference src/alg/matmult/summa/summa.h:24-34,
+// summa.hpp:6-254).
+//
+// Same four invoke() overloads keyed on the blas ArgPack.  Per multiply, rank (x,y,z) of a d x d x c grid receives the
+// A panel of the row-root and the B panel of the column-root of K-class q, multiplies locally on the MFMA tile kernel
+// and sums the partial products over `depth`:
+//     C1 MPI_Bcast(row)  -> capi_bcast(row)      C2 MPI_Bcast(column) -> capi_bcast(column)
+//     K1/K4 cblas_dgemm / cblas_dtrmm -> capi_dgemm / capi_dgemmt / capi_dtrmm_acc
+//     C3 MPI_Allreduce(depth) -> capi_allreduce_sum(depth)      M3 beta-axpy -> capi_dgeadd
+// Differences from the reference, all behind the same results:
+//   * operands are "views" (pointer, leading dimension) into device-resident blocks, so at d == c == 1 the multiply
+//     runs in place with no packing, zero-fill or axpy passes at all;
+//   * the trailing update only computes the triangle that is used (capi_dgemmt) instead of a full GEMM
+//     (summa.hpp:115-146 runs cblas_dgemm and repacks);
+//   * any c dividing d is accepted: layer z owns K-classes q = z, z+c, ... (the reference needs c == d);
+//     d == 1 with c > 1 slices the local K range instead (pure replication, used for the 2-GPU grid).
+#ifndef CAPITAL_MATMULT_SUMMA_H_
+#define CAPITAL_MATMULT_SUMMA_H_
+
+#include "./../../alg.h"
+
+namespace matmult {
+
+// contiguous device scratch handed out stack-wise; sized once per factorisation (the reference's simulate() tables)
+struct arena {
+  double* base = nullptr;
+  int64_t cap = 0, top = 0;
+  ~arena() { capital::dev_free(base); }
+  void reserve(int64_t count) {
+    if (count > cap) {
+      capital::sync();
+      capital::dev_free(base);
+      base = capital::dev_alloc(count);
+      cap = count;
+    }
+    top = 0;
+  }
+  double* take(int64_t count) {
+    count = (count + 1) & ~(int64_t)1;  // keep 16-byte alignment
+    if (top + count > cap) throw std::runtime_error("matmult::arena exhausted (sizing rule out of date)");
+    double* p = base + top;
+    top += count;
+    return p;
+  }
+};
+
+struct view {
+  double* p;
+  int64_t ld, rows, cols;
+  bool contiguous() const { return ld == rows; }
+  int64_t count() const { return rows * cols; }
+};
+
+class summa {
+public:
+  // ---- public overloads on matrix<> objects (summa.h:24-34) ------------------------------------------------------
+  template <typename MatrixAType, typename MatrixBType, typename MatrixCType, typename CommType>
+  static void invoke(MatrixAType& A, MatrixBType& B, MatrixCType& C, CommType&& CommInfo, blas::ArgPack_gemm<typename MatrixAType::ScalarType>& pack) {
+    static_assert(std::is_same<typename MatrixAType::StructureType, rect>::value && std::is_same<typename MatrixBType::StructureType, rect>::value &&
+                      std::is_same<typename MatrixCType::StructureType, rect>::value,
+                  "summa gemm works on rect blocks (the reference's callers only pass rect: cacqr.hpp:62, validate.hpp)");
+    arena& ws = scratch_arena();
+    ws.reserve(2 * (A.num_elems() + B.num_elems() + C.num_elems()) + 64);
+    gemm(CommInfo, (int)pack.transposeA, (int)pack.transposeB, pack.alpha, as_view(A), as_view(B), pack.beta, as_view(C), ws);
+  }
+  // B <- alpha * op(A) * B  or  alpha * B * op(A), A triangular (summa.hpp:46-83)
+  template <typename MatrixAType, typename MatrixBType, typename CommType>
+  static void invoke(MatrixAType& A, MatrixBType& B, CommType&& CommInfo, blas::ArgPack_trmm<typename MatrixAType::ScalarType>& pack) {
+    static_assert(std::is_same<typename MatrixAType::StructureType, rect>::value && std::is_same<typename MatrixBType::StructureType, rect>::value,
+                  "packed operands are unpacked by the algorithm layer before they reach the device summa");
+    arena& ws = scratch_arena();
+    ws.reserve(3 * A.num_elems() + 4 * B.num_elems() + 64);
+    view out{ws.take(B.num_elems()), B.num_rows_local(), B.num_rows_local(), B.num_columns_local()};
+    trmm(CommInfo, (int)pack.side, (int)pack.uplo, (int)pack.transposeA, (int)pack.diag, pack.alpha, as_view(A), as_view(B), out, ws);
+    capital::dev_copy(B.data(), out.p, B.num_elems());
+  }
+  // C <- alpha * A^T A + beta * C (or A A^T), summa.hpp:85-96: the second operand is the partner-exchanged copy of A
+  template <typename MatrixSrcType, typename MatrixDestType, typename CommType>
+  static void invoke(MatrixSrcType& A, MatrixDestType& C, CommType&& CommInfo, blas::ArgPack_syrk<typename MatrixSrcType::ScalarType>& pack) {
+    MatrixSrcType B = A;
+    invoke(A, B, C, CommInfo, pack);
+  }
+  // summa.hpp:98-109: B is exchanged with the transpose partner, then the triangular-output multiply
+  template <typename MatrixSrcType, typename MatrixDestType, typename CommType>
+  static void invoke(MatrixSrcType& A, MatrixSrcType& B, MatrixDestType& C, CommType&& CommInfo, blas::ArgPack_syrk<typename MatrixSrcType::ScalarType>& pack) {
+    static_assert(std::is_same<typename MatrixSrcType::StructureType, rect>::value && std::is_same<typename MatrixDestType::StructureType, rect>::value,
+                  "packed operands are unpacked by the algorithm layer before they reach the device summa");
+    util::transpose(B, CommInfo);
+    arena& ws = scratch_arena();
+    ws.reserve(2 * (A.num_elems() + B.num_elems() + C.num_elems()) + 64);
+    syrk(CommInfo, (int)pack.uplo, (int)pack.transposeA, pack.alpha, as_view(A), as_view(B), pack.beta, as_view(C), ws);
+  }
+
+  // ---- view-level engine (used directly by cholinv / cacqr) ---------------------------------------------------------
+  // C <- alpha*op(A)*op(B) + beta*C.  Operand blocks are the LOCAL blocks of this rank; roots are chosen per K-class.
+  template <typename CommType>
+  static void gemm(CommType&& t, int transA, int transB, double alpha, view A, view B, double beta, view C, arena& ws) {
+    capi_handle_t h = capital::handle();
+    const int64_t M = C.rows, N = C.cols, K = transA ? A.rows : A.cols;
+    if (t.d == 1 && t.c == 1) {
+      CAPITAL_CHECK(capi_dgemm(h, transA, transB, M, N, K, alpha, A.p, A.ld, B.p, B.ld, beta, C.p, C.ld));
+      return;
+    }
+    const int64_t mark = ws.top;
+    view acc = t.c > 1 ? view{ws.take(M * N), M, M, N} : C;
+    if (t.d == 1) {
+      // pure replication: layer z multiplies its slice of the local K range
+      int64_t k0, k1;
+      kslice(K, t.c, t.z, k0, k1);
+      const double* a = transA ? A.p + k0 : A.p + k0 * A.ld;
+      const double* b = transB ? B.p + k0 * B.ld : B.p + k0;
+      CAPITAL_CHECK(capi_dgemm(h, transA, transB, M, N, k1 - k0, alpha, a, A.ld, b, B.ld, 0.0, acc.p, acc.ld));
+    } else {
+      const size_t steps = t.d / t.c;
+      for (size_t s = 0; s < steps; ++s) {
+        const size_t q = t.z + s * t.c;
+        view a = panel(t.row, t.x == q, (int)q, A, ws), b = panel(t.column, t.y == q, (int)q, B, ws);
+        const double bt = (t.c > 1) ? (s ? 1.0 : 0.0) : (s ? 1.0 : beta);
+        CAPITAL_CHECK(capi_dgemm(h, transA, transB, M, N, K, alpha, a.p, a.ld, b.p, b.ld, bt, acc.p, acc.ld));
+      }
+    }
+    if (t.c > 1) {
+      CAPITAL_CHECK(capi_allreduce_sum(t.depth, acc.p, acc.count()));
+      CAPITAL_CHECK(capi_dgeadd(h, 0, M, N, 1.0, acc.p, acc.ld, beta, C.p, C.ld));
+    }
+    ws.top = mark;
+  }
+
+  // Cout <- alpha*op(T)*B (Left) or alpha*B*op(T) (Right); T is this rank's block of a triangular matrix.
+  // Left: T travels along `row`, B along `column`; Right: B along `row`, T along `column` (summa.hpp:59-71).
+  template <typename CommType>
+  static void trmm(CommType&& t, int side, int uplo, int trans, int diag, double alpha, view T, view B, view Cout, arena& ws) {
+    capi_handle_t h = capital::handle();
+    const int64_t M = B.rows, N = B.cols;
+    if (t.d == 1 && t.c == 1) {
+      CAPITAL_CHECK(capi_dtrmm_oop(h, side, uplo, trans, diag, M, N, alpha, T.p, T.ld, B.p, B.ld, Cout.p, Cout.ld));
+      return;
+    }
+    const int64_t mark = ws.top;
+    if (t.d == 1) {
+      // K-slice [k0,k1) of a triangular operand: a triangle on the diagonal plus a rectangle beside it
+      const int64_t K = T.rows;
+      int64_t k0, k1;
+      kslice(K, t.c, t.z, k0, k1);
+      const bool eff_upper = (uplo == CAPI_UPPER) != (trans == CAPI_TRANS);
+      CAPITAL_CHECK(capi_dgeadd(h, 0, M, N, 0.0, Cout.p, Cout.ld, 0.0, Cout.p, Cout.ld));   // Cout = 0
+      if (k1 > k0) {
+        const double* Tkk = T.p + k0 + k0 * T.ld;
+        if (side == CAPI_LEFT) {
+          // rows of op(T) that see K-columns [k0,k1): the diagonal block rows [k0,k1) and, above (eff upper) or below them, a rectangle
+          CAPITAL_CHECK(capi_dtrmm_oop(h, side, uplo, trans, diag, k1 - k0, N, alpha, Tkk, T.ld, B.p + k0, B.ld, Cout.p + k0, Cout.ld));
+          const int64_t r0 = eff_upper ? 0 : k1, r1 = eff_upper ? k0 : K;
+          if (r1 > r0) {
+            // E[r0:r1, k0:k1] = trans ? T[k0:k1, r0:r1]^T : T[r0:r1, k0:k1]
+            const double* Tr = trans ? T.p + k0 + r0 * T.ld : T.p + r0 + k0 * T.ld;
+            CAPITAL_CHECK(capi_dgemm(h, trans, CAPI_NOTRANS, r1 - r0, N, k1 - k0, alpha, Tr, T.ld, B.p + k0, B.ld, 0.0, Cout.p + r0, Cout.ld));
+          }
+        } else {
+          CAPITAL_CHECK(capi_dtrmm_oop(h, side, uplo, trans, diag, M, k1 - k0, alpha, Tkk, T.ld, B.p + k0 * B.ld, B.ld, Cout.p + k0 * Cout.ld, Cout.ld));
+          const int64_t c0 = eff_upper ? k1 : 0, c1 = eff_upper ? K : k0;
+          if (c1 > c0) {
+            // E[k0:k1, c0:c1] = trans ? T[c0:c1, k0:k1]^T : T[k0:k1, c0:c1]
+            const double* Tr = trans ? T.p + c0 + k0 * T.ld : T.p + k0 + c0 * T.ld;
+            CAPITAL_CHECK(capi_dgemm(h, CAPI_NOTRANS, trans, M, c1 - c0, k1 - k0, alpha, B.p + k0 * B.ld, B.ld, Tr, T.ld, 0.0, Cout.p + c0 * Cout.ld, Cout.ld));
+          }
+        }
+      }
+    } else {
+      const size_t steps = t.d / t.c;
+      for (size_t s = 0; s < steps; ++s) {
+        const size_t q = t.z + s * t.c;
+        view tt, bb;
+        if (side == CAPI_LEFT) { tt = panel(t.row, t.x == q, (int)q, T, ws); bb = panel(t.column, t.y == q, (int)q, B, ws); }
+        else { bb = panel(t.row, t.x == q, (int)q, B, ws); tt = panel(t.column, t.y == q, (int)q, T, ws); }
+        CAPITAL_CHECK(capi_dtrmm_acc(h, side, uplo, trans, diag, M, N, alpha, tt.p, tt.ld, bb.p, bb.ld, s ? 1.0 : 0.0, Cout.p, Cout.ld));
+      }
+    }
+    if (t.c > 1) allreduce_view(t.depth, Cout, ws);
+    ws.top = mark;
+  }
+
+  // C(uplo) <- alpha * Bx^T * A + beta*C (trans) or alpha * A * Bx^T + beta*C; Bx = partner-exchanged block (summa.hpp:111-158)
+  template <typename CommType>
+  static void syrk(CommType&& t, int uplo, int trans, double alpha, view A, view Bx, double beta, view C, arena& ws) {
+    capi_handle_t h = capital::handle();
+    const int64_t N = C.cols, K = trans ? A.rows : A.cols;
+    // operand order of the local multiply (summa.hpp:137-146)
+    const int tA = trans ? CAPI_TRANS : CAPI_NOTRANS, tB = trans ? CAPI_NOTRANS : CAPI_TRANS;
+    if (t.d == 1 && t.c == 1) {
+      const view& L = trans ? Bx : A;
+      const view& Rr = trans ? A : Bx;
+      CAPITAL_CHECK(capi_dgemmt(h, uplo, tA, tB, N, K, alpha, L.p, L.ld, Rr.p, Rr.ld, beta, C.p, C.ld));
+      return;
+    }
+    const int64_t mark = ws.top;
+    view acc = t.c > 1 ? view{ws.take(N * N), N, N, N} : C;
+    if (t.d == 1) {
+      int64_t k0, k1;
+      kslice(K, t.c, t.z, k0, k1);
+      const view& L = trans ? Bx : A;
+      const view& Rr = trans ? A : Bx;
+      const double* l = trans ? L.p + k0 : L.p + k0 * L.ld;
+      const double* r = trans ? Rr.p + k0 : Rr.p + k0 * Rr.ld;
+      CAPITAL_CHECK(capi_dgemmt(h, uplo, tA, tB, N, k1 - k0, alpha, l, L.ld, r, Rr.ld, 0.0, acc.p, acc.ld));
+    } else {
+      const size_t steps = t.d / t.c;
+      for (size_t s = 0; s < steps; ++s) {
+        const size_t q = t.z + s * t.c;
+        view l, r;
+        if (trans) { l = panel(t.row, t.x == q, (int)q, Bx, ws); r = panel(t.column, t.y == q, (int)q, A, ws); }   // distribute(B,A)
+        else { l = panel(t.row, t.x == q, (int)q, A, ws); r = panel(t.column, t.y == q, (int)q, Bx, ws); }        // distribute(A,B)
+        const double bt = (t.c > 1) ? (s ? 1.0 : 0.0) : (s ? 1.0 : beta);
+        CAPITAL_CHECK(capi_dgemmt(h, uplo, tA, tB, N, K, alpha, l.p, l.ld, r.p, r.ld, bt, acc.p, acc.ld));
+      }
+    }
+    if (t.c > 1) {
+      // only the computed triangle is summed over depth and folded into C
+      CAPITAL_CHECK(capi_allreduce_sum(t.depth, acc.p, acc.count()));
+      CAPITAL_CHECK(capi_dgeadd(h, uplo == CAPI_UPPER ? 1 : 2, N, N, 1.0, acc.p, acc.ld, beta, C.p, C.ld));
+    }
+    ws.top = mark;
+  }
+
+  static arena& scratch_arena() {
+    static arena a;
+    return a;
+  }
+  template <typename MatrixType>
+  static view as_view(MatrixType& m) { return view{m.data(), m.num_rows_local(), m.num_rows_local(), m.num_columns_local()}; }
+
+  // [k0,k1): slice z of c equal (even-sized, for 16-byte alignment) pieces of a local K range
+  static void kslice(int64_t K, size_t c, size_t z, int64_t& k0, int64_t& k1) {
+    int64_t per = ((K + (int64_t)c - 1) / (int64_t)c + 1) & ~(int64_t)1;
+    k0 = std::min<int64_t>(K, per * (int64_t)z);
+    k1 = std::min<int64_t>(K, k0 + per);
+  }
+
+private:
+  // The panel a rank multiplies with: the root's own block (packed to contiguous if it is a strided view) broadcast
+  // over `comm`.  Non-roots receive into arena memory.  Blocks have equal shapes on all ranks of a communicator.
+  static view panel(capi_comm_t comm, bool is_root, int root, const view& mine, arena& ws) {
+    int size = 1;
+    CAPITAL_CHECK(capi_comm_size(comm, &size));
+    if (size == 1) return mine;
+    view out{nullptr, mine.rows, mine.rows, mine.cols};
+    if (is_root && mine.contiguous()) {
+      out.p = mine.p;
+    } else {
+      out.p = ws.take(mine.count());
+      if (is_root) CAPITAL_CHECK(capi_dlacpy(capital::handle(), 0, mine.rows, mine.cols, mine.p, mine.ld, out.p, out.ld));
+    }
+    CAPITAL_CHECK(capi_bcast(comm, out.p, out.count(), root));
+    return out;
+  }
+  static void allreduce_view(capi_comm_t comm, view v, arena& ws) {
+    if (v.contiguous()) { CAPITAL_CHECK(capi_allreduce_sum(comm, v.p, v.count())); return; }
+    double* tmp = ws.take(v.count());
+    CAPITAL_CHECK(capi_dlacpy(capital::handle(), 0, v.rows, v.cols, v.p, v.ld, tmp, v.rows));
+    CAPITAL_CHECK(capi_allreduce_sum(comm, tmp, v.count()));
+    CAPITAL_CHECK(capi_dlacpy(capital::handle(), 0, v.rows, v.cols, tmp, v.rows, v.p, v.ld));
+  }
+};
+
+}  // namespace matmult
+
+#endif  // CAPITAL_MATMULT_SUMMA_H_

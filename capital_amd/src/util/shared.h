@@ -1,0 +1,103 @@
+// shared.h -- process-wide context of the host-side C++ layer (one process per GPU).
+//
+// Takes the place of the reference's src/util/shared.h (which pulls in <mpi.h> and "mkl.h"): here the two
+// external dependencies are the C-ABI of libcapital_hip.so (device BLAS/LAPACK/data movement) and its RCCL-backed
+// communicators.  MPI_COMM_WORLD becomes capital::world(); MPI_Init becomes capital::init().
+#ifndef CAPITAL_SHARED_H_
+#define CAPITAL_SHARED_H_
+
+#include <algorithm>
+#include <cassert>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+#include "capital_hip.h"
+
+// Region markers of the reference's external profiler (shared.h:26-35) are kept as no-op hooks.
+#ifndef CRITTER_START
+#define CRITTER_START(ARG)
+#define CRITTER_STOP(ARG)
+#endif
+
+namespace capital {
+
+struct context {
+  capi_handle_t handle = nullptr;
+  capi_comm_t world = nullptr;
+  int rank = 0, size = 1, device = 0;
+  bool owns_handle = false;
+};
+
+inline context& ctx() {
+  static context c;
+  return c;
+}
+
+inline void check(int rc, const char* what) {
+  if (rc != CAPI_OK) {
+    const char* msg = ctx().handle ? capi_last_error(ctx().handle) : "";
+    char buf[768];
+    snprintf(buf, sizeof(buf), "capital: %s failed (status %d) %s", what, rc, msg);
+    throw std::runtime_error(buf);
+  }
+}
+#define CAPITAL_CHECK(call) ::capital::check((call), #call)
+
+// Bind the layer to an existing handle (e.g. one living on torch's stream) and, for size > 1, to a world
+// communicator built from a 128-byte RCCL unique id that the launcher distributed.
+inline void init_with_handle(capi_handle_t h, int rank, int size, const void* unique_id) {
+  context& c = ctx();
+  c.handle = h;
+  c.rank = rank;
+  c.size = size;
+  if (c.world) { capi_comm_destroy(c.world); c.world = nullptr; }
+  CAPITAL_CHECK(capi_comm_init_rank(&c.world, h, size, unique_id, rank));
+}
+inline void init(int device, int rank, int size, const void* unique_id) {
+  capi_handle_t h;
+  int rc = capi_create(&h, device);
+  if (rc != CAPI_OK) throw std::runtime_error("capital: capi_create failed (is a GPU visible and libcapital_hip.so built?)");
+  ctx().owns_handle = true;
+  ctx().device = device;
+  init_with_handle(h, rank, size, unique_id);
+}
+inline void finalize() {
+  context& c = ctx();
+  if (c.world) { capi_comm_destroy(c.world); c.world = nullptr; }
+  if (c.handle && c.owns_handle) capi_destroy(c.handle);
+  c.handle = nullptr;
+  c.owns_handle = false;
+}
+inline capi_handle_t handle() {
+  if (!ctx().handle) throw std::runtime_error("capital: call capital::init() first");
+  return ctx().handle;
+}
+inline capi_comm_t world() { return ctx().world; }
+inline void sync() { CAPITAL_CHECK(capi_sync(handle())); }
+
+// Device buffer with value semantics of a raw pointer + ownership flag (the reference's new[]/delete[]).
+inline double* dev_alloc(int64_t count) {
+  void* p = nullptr;
+  CAPITAL_CHECK(capi_malloc(handle(), &p, sizeof(double) * (size_t)std::max<int64_t>(count, 1)));
+  return (double*)p;
+}
+inline void dev_free(double* p) {
+  if (p && ctx().handle) capi_free(ctx().handle, p);
+}
+inline void dev_zero(double* p, int64_t count) { CAPITAL_CHECK(capi_memset_async(handle(), p, 0, sizeof(double) * (size_t)count)); }
+inline void dev_copy(double* dst, const double* src, int64_t count) {
+  CAPITAL_CHECK(capi_memcpy_d2d_async(handle(), dst, src, sizeof(double) * (size_t)count));
+}
+
+}  // namespace capital
+
+#endif  // CAPITAL_SHARED_H_

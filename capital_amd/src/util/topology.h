@@ -1,0 +1,104 @@
+// util/topology.h -- processor grids on the GPUs of one node (reference src/util/topology.h:16-143).
+//
+// topo::square is the d x d x c grid of the recursive Cholesky / 3-D SUMMA, topo::rect the tunable c x d x c grid of
+// CA-CholeskyQR2.  Rank -> (x,y,z) maps and the sub-communicator memberships are the reference's; the communicators
+// are RCCL ones (capi_comm_split) living on the context's HIP stream, one process per GPU.  On a fully connected xGMI
+// node the row / column / depth partners of a 2x2x2 grid are three different peers, i.e. three different links.
+//
+// Beyond the reference: it only supports cubic grids for Cholesky (c == d; its SUMMA roots are x==z / y==z).  Here any
+// c that divides d is accepted (layer z owns the K-classes q = z, z+c, ...), which gives 4-GPU (d=2,c=1) and, with
+// d == 1, pure K-replication (2-GPU: d=1,c=2) decompositions -- see matmult::summa.
+#ifndef CAPITAL_TOPOLOGY_H_
+#define CAPITAL_TOPOLOGY_H_
+
+#include "shared.h"
+
+namespace topo {
+
+namespace detail {
+inline capi_comm_t split(capi_comm_t parent, int color, int key) {
+  capi_comm_t c = nullptr;
+  CAPITAL_CHECK(capi_comm_split(parent, color, key, &c));
+  return c;
+}
+inline void release(capi_comm_t& c) { if (c) { capi_comm_destroy(c); c = nullptr; } }
+inline size_t isqrt_ceil(size_t v) { size_t r = (size_t)std::llround(std::ceil(std::sqrt((double)v))); while (r * r < v) ++r; while (r > 0 && (r - 1) * (r - 1) >= v) --r; return r; }
+}  // namespace detail
+
+class square {
+public:
+  // comm: parent communicator (capital::world()); c: replication depth; layout as in the reference (0,1 supported)
+  square(capi_comm_t comm, size_t c_, size_t layout_ = 0, size_t num_chunks_ = 0) : c(c_), layout(layout_), num_chunks(num_chunks_) {
+    CAPITAL_CHECK(capi_comm_rank(comm, &rank));
+    CAPITAL_CHECK(capi_comm_size(comm, &size));
+    if (c == 0 || size % (int)c) throw std::invalid_argument("topo::square: c must divide the communicator size");
+    d = detail::isqrt_ceil(size / c);                                   // topology.h:77
+    if (d * d * c != (size_t)size) throw std::invalid_argument("topo::square: size must be d*d*c");
+    const size_t TopFaceSize = d * c, FrontFaceSize = d * d;
+    if (layout == 0) {                                                  // topology.h:80-95
+      z = rank % c; y = rank / TopFaceSize; x = (rank % TopFaceSize) / c;
+    } else if (layout == 1) {                                           // topology.h:96-103
+      y = rank % d; x = (rank % FrontFaceSize) / d; z = rank / FrontFaceSize;
+    } else {
+      throw std::invalid_argument("topo::square: layout 2 (64-rank sub-cubes, topology.h:104-123) is a multi-node layout; not offered on one node");
+    }
+    world = comm;
+    depth = detail::split(comm, (int)(x + d * y), (int)z);              // same (x,y), ordered by z
+    slice = detail::split(comm, (int)z, (int)(x + d * y));              // same z; slice rank = x + d*y
+    row = detail::split(slice, (int)y, (int)x);                         // same y (and z), ordered by x
+    column = detail::split(slice, (int)x, (int)y);                      // same x (and z), ordered by y
+  }
+  square(const square&) = delete;
+  square& operator=(const square&) = delete;
+  ~square() { detail::release(row); detail::release(column); detail::release(slice); detail::release(depth); }
+
+  // world rank of grid position (x,y,z) under this layout (util::transpose's partner rule, util.hpp:237-239)
+  int rank_of(size_t px, size_t py, size_t pz) const {
+    return layout == 0 ? (int)(pz + c * px + c * d * py) : (int)(py + d * px + d * d * pz);
+  }
+
+  capi_comm_t world = nullptr, row = nullptr, column = nullptr, slice = nullptr, depth = nullptr;
+  int rank = 0, size = 1;
+  size_t c = 1, d = 1, x = 0, y = 0, z = 0, layout = 0, num_chunks = 0;
+};
+
+class rect {
+public:
+  // c x d x c grid over `comm` (topology.h:16-65).  With c == 1 (the 1-D CholeskyQR2 of BASELINE configs 3 and 5) only
+  // `world` carries traffic; the cube / row / column_* / depth communicators matter for the 3-D variants.
+  rect(capi_comm_t comm, size_t c_, size_t layout_ = 0, size_t num_chunks_ = 0) : c(c_), layout(layout_), num_chunks(num_chunks_) {
+    CAPITAL_CHECK(capi_comm_rank(comm, &rank));
+    CAPITAL_CHECK(capi_comm_size(comm, &size));
+    if (c == 0 || size % (int)(c * c)) throw std::invalid_argument("topo::rect: c*c must divide the communicator size");
+    const size_t SubCubeSize = c * c * c, SubCubeSliceSize = c * c;
+    world = comm;
+    d = size / (c * c);
+    z = rank % c; y = rank / SubCubeSliceSize; x = (rank % SubCubeSliceSize) / c;   // topology.h:46-50
+    cube = detail::split(comm, (int)(rank / SubCubeSize), rank);
+    int cubeRank = 0;
+    CAPITAL_CHECK(capi_comm_rank(cube, &cubeRank));
+    depth = detail::split(cube, (int)(cubeRank / c), cubeRank);
+    row = detail::split(cube, (int)((cubeRank % c) + c * (cubeRank / SubCubeSliceSize)), cubeRank);
+    capi_comm_t column = detail::split(comm, (int)(rank % SubCubeSliceSize), rank);
+    slice = detail::split(comm, (int)(rank % c), rank);
+    int columnRank = 0;
+    CAPITAL_CHECK(capi_comm_rank(column, &columnRank));
+    column_contig = detail::split(column, (int)(columnRank / c), columnRank);
+    column_alt = detail::split(column, (int)(columnRank % c), columnRank);
+    detail::release(column);
+  }
+  rect(const rect&) = delete;
+  rect& operator=(const rect&) = delete;
+  ~rect() {
+    detail::release(row); detail::release(column_contig); detail::release(column_alt);
+    detail::release(depth); detail::release(slice); detail::release(cube);
+  }
+
+  capi_comm_t world = nullptr, row = nullptr, column_contig = nullptr, column_alt = nullptr, depth = nullptr, slice = nullptr, cube = nullptr;
+  int rank = 0, size = 1;
+  size_t c = 1, d = 1, x = 0, y = 0, z = 0, layout = 0, num_chunks = 0;
+};
+
+}  // namespace topo
+
+#endif  // CAPITAL_TOPOLOGY_H_

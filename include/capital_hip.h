@@ -80,6 +80,9 @@ int capi_dtrmm(capi_handle_t h, int side, int uplo, int trans, int diag, int64_t
 /* Out-of-place form used on the hot path: C <- alpha*op(T)*B or alpha*B*op(T); C must not alias B. */
 int capi_dtrmm_oop(capi_handle_t h, int side, int uplo, int trans, int diag, int64_t m, int64_t n, double alpha,
                    const double* T, int64_t ldt, const double* B, int64_t ldb, double* C, int64_t ldc);
+/* accumulating form for multi-step SUMMA (d/c > 1 K-panels per layer): C <- alpha*op(T)*B + beta*C */
+int capi_dtrmm_acc(capi_handle_t h, int side, int uplo, int trans, int diag, int64_t m, int64_t n, double alpha,
+                   const double* T, int64_t ldt, const double* B, int64_t ldb, double beta, double* C, int64_t ldc);
 /* B <- alpha*op(T)^-1*B or alpha*B*op(T)^-1.  Not in the reference (it forms trtri+trmm instead,
  * SURVEY.md quick facts); named by BASELINE.json north_star. */
 int capi_dtrsm(capi_handle_t h, int side, int uplo, int trans, int diag, int64_t m, int64_t n, double alpha,
@@ -103,8 +106,16 @@ int capi_reset_info(capi_handle_t h);
 int capi_serialize(capi_handle_t h, int src_struct, int dst_struct,
                    const double* src, int64_t sdimX, int64_t sdimY, double* dst, int64_t ddimX, int64_t ddimY,
                    int64_t ssx, int64_t sex, int64_t ssy, int64_t sey, int64_t dsx, int64_t dex, int64_t dsy, int64_t dey);
+/* same, with the copy SHAPE (rect: whole columns, uppertri: i+1 leading entries of column i, lowertri: from the
+ * diagonal down) given separately from the two storage layouts -- the reference applies serialize<uppertri,uppertri>
+ * to rect-stored matrices too (cholinv.hpp:13) */
+int capi_serialize_shape(capi_handle_t h, int shape, int src_struct, int dst_struct,
+                         const double* src, int64_t sdimX, int64_t sdimY, double* dst, int64_t ddimX, int64_t ddimY,
+                         int64_t ssx, int64_t sex, int64_t ssy, int64_t sey, int64_t dsx, int64_t dex, int64_t dsy, int64_t dey);
 /* B <- A for an m x n block; part: 0 all, 1 upper triangle incl. diagonal, 2 lower incl. diagonal */
 int capi_dlacpy(capi_handle_t h, int part, int64_t m, int64_t n, const double* A, int64_t lda, double* B, int64_t ldb);
+/* Y(part) <- alpha*X + beta*Y on an m x n block (the beta-update after summa's Allreduce, summa.hpp:33,153) */
+int capi_dgeadd(capi_handle_t h, int part, int64_t m, int64_t n, double alpha, const double* X, int64_t ldx, double beta, double* Y, int64_t ldy);
 /* zero the strictly lower (uplo=Upper keeps upper) or strictly upper part of an n x n block */
 int capi_dtrizero(capi_handle_t h, int keep_uplo, int64_t n, double* A, int64_t lda);
 /* y <- beta*y + x over count elements (M3) */

@@ -59,8 +59,8 @@ def test_dgemm_beta0_ignores_nan(hip, oracle):
     rng = np.random.default_rng(5)
     m = n = k = 96
     A, B = _rand(rng, m, k), _rand(rng, k, n)
-    dC = capi.to_device(np.full((m, n), np.nan))
-    hip.call("capi_dgemm", 0, 0, m, n, k, 1.0, capi.ptr(capi.to_device(A)), m, capi.ptr(capi.to_device(B)), k, 0.0, capi.ptr(dC), m)
+    dA, dB, dC = capi.to_device(A), capi.to_device(B), capi.to_device(np.full((m, n), np.nan))
+    hip.call("capi_dgemm", 0, 0, m, n, k, 1.0, capi.ptr(dA), m, capi.ptr(dB), k, 0.0, capi.ptr(dC), m)
     _check(capi.to_host(dC), A @ B, k)
 
 
@@ -126,8 +126,8 @@ def test_dgemmt(hip, oracle, uplo, ta, tb):
     Cm = _rand(rng, n, n)
     ref = Cm.copy(order="F")
     oracle.dgemm(ta, tb, 2.0, A, B, 0.5, ref)
-    dC = capi.to_device(Cm)
-    hip.call("capi_dgemmt", uplo, ta, tb, n, k, 2.0, capi.ptr(capi.to_device(A)), A.shape[0], capi.ptr(capi.to_device(B)), B.shape[0], 0.5, capi.ptr(dC), n)
+    dA, dB, dC = capi.to_device(A), capi.to_device(B), capi.to_device(Cm)
+    hip.call("capi_dgemmt", uplo, ta, tb, n, k, 2.0, capi.ptr(dA), A.shape[0], capi.ptr(dB), B.shape[0], 0.5, capi.ptr(dC), n)
     got = capi.to_host(dC)
     tri = np.triu(np.ones((n, n), bool)) if uplo else np.tril(np.ones((n, n), bool))
     _check(got[tri], ref[tri], k)
@@ -157,7 +157,7 @@ def test_dtrsm(hip, oracle, side, uplo, trans, diag, m, n):
     from capital_amd import capi
     rng = np.random.default_rng(side * 8 + uplo * 4 + trans * 2 + diag + m)
     nt = m if side == 0 else n
-    T = _rand(rng, nt, nt) * 0.1 + np.eye(nt) * 4.0   # well conditioned
+    T = np.asfortranarray(_rand(rng, nt, nt) * 0.1 + np.eye(nt) * 4.0)   # well conditioned
     B = _rand(rng, m, n)
     ref = B.copy(order="F")
     oracle.dtrsm(side, uplo, trans, diag, 0.5, T, ref)

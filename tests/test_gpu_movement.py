@@ -69,8 +69,8 @@ def test_lacpy_trizero_axpby_remove_triangle(hip, oracle):
     m, n = 150, 140
     A, B = rng.uniform(size=(m, n)), rng.uniform(size=(m, n))
     for part in (0, 1, 2):
-        dB = capi.to_device(B)
-        hip.call("capi_dlacpy", part, m, n, capi.ptr(capi.to_device(A)), m, capi.ptr(dB), m)
+        dA, dB = capi.to_device(A), capi.to_device(B)
+        hip.call("capi_dlacpy", part, m, n, capi.ptr(dA), m, capi.ptr(dB), m)
         i, j = np.indices((m, n))
         sel = np.ones((m, n), bool) if part == 0 else (i <= j if part == 1 else i >= j)
         np.testing.assert_array_equal(capi.to_host(dB), np.where(sel, A, B))
@@ -110,8 +110,8 @@ def test_block_cyclic(hip, oracle, rl, d):
     full = rng.uniform(size=ref.size)
     back = np.zeros_like(blocked)
     oracle.lib().orc_cyclic_to_block_rect(back.ctypes.data_as(dp), full.ctypes.data_as(dp), rl, rl, d)
-    db2 = torch.zeros(blocked.size, dtype=torch.float64, device="cuda")
-    hip.call("capi_cyclic_to_block", capi.ptr(db2), capi.ptr(torch.from_numpy(full).cuda()), rl, rl, d)
+    db2, dfull = torch.zeros(blocked.size, dtype=torch.float64, device="cuda"), torch.from_numpy(full).cuda()
+    hip.call("capi_cyclic_to_block", capi.ptr(db2), capi.ptr(dfull), rl, rl, d)
     np.testing.assert_array_equal(db2.cpu().numpy(), back)
 
 
@@ -122,7 +122,8 @@ def test_diff_norms(hip, oracle):
     X, Y = rng.uniform(size=(m, n)), rng.uniform(size=(m, n))
     import ctypes as C
     out = (C.c_double * 2)()
-    hip.call("capi_diff_norms", 1, m, n, capi.ptr(capi.to_device(X)), m, capi.ptr(capi.to_device(Y)), m, out)
+    dX, dY = capi.to_device(X), capi.to_device(Y)
+    hip.call("capi_diff_norms", 1, m, n, capi.ptr(dX), m, capi.ptr(dY), m, out)
     i, j = np.indices((m, n))
     sel = i <= j
     assert abs(out[0] - ((X - Y)[sel] ** 2).sum()) <= 1e-10 and abs(out[1] - (Y[sel] ** 2).sum()) <= 1e-10

@@ -1,0 +1,70 @@
+"""GPU parity of the two schedules through the C-ABI driver (capital_amd/drivers): recursive Cholesky-with-inverse
+(cholinv.hpp:6-183) and 1-D CholeskyQR2 (cacqr.hpp:7-29,174-193) against the CPU oracle on the reference's own
+generators.  Tolerances are the ones SURVEY.md 8c states: elementwise 1e-12 relative for R / R^-1 / Q, Cholesky
+residual <= 1e-14, CQR2 residual <= 1e-14, orthogonality <= 1e-15."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def drv():
+    from capital_amd import driver
+    driver.init(0, 0, 1, None, use_torch_stream=False)
+    yield driver
+    driver.finalize()
+
+
+@pytest.mark.parametrize("serialize", (True, False))
+@pytest.mark.parametrize("n,bc,ci,split", [(256, 0, 0, 1), (512, -1, 0, 1), (512, -2, 1, 1), (1000, -3, 0, 1), (1024, -4, 1, 1), (768, -3, 1, 2), (2048, -5, 0, 1)])
+def test_cholinv_matches_oracle(drv, oracle, n, bc, ci, split, serialize):
+    p = drv.Cholinv(n, c=1, complete_inv=ci, split=split, bc_mult=bc, serialize=serialize, bc_policy=2)
+    p.generate()
+    A = p.A()
+    np.testing.assert_array_equal(A, oracle.distribute_symmetric(n, n, 0, 0, 1, 1))     # same input, bit for bit
+    p.factor()
+    R, Ri = p.R(), p.Rinv()
+    Rref, Riref, info = oracle.cholinv_factor(A, ci, split, bc, 1, 1)
+    assert info == 0
+    assert np.abs(R - Rref).max() <= 1e-12 * np.abs(Rref).max()
+    assert np.abs(Ri - Riref).max() <= 1e-12 * np.abs(Riref).max()
+    # structure: strictly lower parts are zero; without complete_inv the top-level off-diagonal block of R^-1 stays zero
+    assert np.all(np.tril(R, -1) == 0) and np.all(np.tril(Ri, -1) == 0)
+    assert (np.count_nonzero(Ri) == np.count_nonzero(Riref))
+    res = p.residual()
+    assert res <= 1e-14 and abs(res - oracle.cholesky_residual(A, Rref)) <= 5e-16
+    st = p.stats()
+    assert st["bc_dimension"] == oracle.cholinv_bc_dimension(n, 1, 1, bc)
+    p.close()
+
+
+def test_cholinv_repeat_is_deterministic(drv, oracle):
+    p = drv.Cholinv(768, bc_mult=-2, serialize=False)
+    p.generate()
+    p.factor()
+    R1 = p.R()
+    p.factor()
+    np.testing.assert_array_equal(R1, p.R())
+    p.close()
+
+
+@pytest.mark.parametrize("serialize", (True, False))
+@pytest.mark.parametrize("m,n,variant", [(4096, 64, 2), (65536, 256, 2), (50001, 130, 2), (8192, 32, 1), (20000, 512, 2)])
+def test_cacqr_1d_matches_oracle(drv, oracle, m, n, variant, serialize):
+    p = drv.Cacqr(m, n, c=1, variant=variant, serialize=serialize)
+    p.generate()
+    A = p.A()
+    np.testing.assert_array_equal(A, oracle.distribute_random(n, m, 0, 0, 1, 1, key=0))
+    p.factor()
+    Q, R = p.Q(), p.R()
+    Qref, Rref, info = oracle.cacqr_factor_1d(A, 1, variant)
+    assert info == 0
+    assert np.abs(R - Rref).max() <= 1e-12 * np.abs(Rref).max()
+    assert np.abs(Q - Qref).max() <= 1e-12 * max(1.0, np.abs(Qref).max()) * (1 if variant == 2 else 50)
+    assert np.all(np.tril(R, -1) == 0)
+    if variant == 2:
+        assert p.residual() <= 1e-14
+        assert p.orthogonality() <= 1e-15
+        assert abs(p.residual() - oracle.qr_residual(A, Qref, Rref)) <= 5e-16
+    p.close()

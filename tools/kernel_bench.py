@@ -1,7 +1,10 @@
 """Per-kernel timing on the GPU box (not the judged bench): fp64 MFMA peak loop, GEMM/GEMMT/TRMM tile kernel."""
 import ctypes as C
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import torch
 from capital_amd import capi

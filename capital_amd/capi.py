@@ -49,6 +49,8 @@ _SIGS = {
     "capi_distribute_identity": [_vp] + [_i64] * 8 + [_dbl],
     "capi_diff_norms": [_int, _i64, _i64, _vp, _i64, _vp, _i64, C.POINTER(_dbl)],
     "capi_mfma_f64_peak": [_int, C.POINTER(_dbl)],
+    "capi_prof_enable": [_int],
+    "capi_prof_collect": [_int, C.POINTER(_i64), C.POINTER(_dbl), C.POINTER(_dbl), C.POINTER(_dbl)],
     "capi_timer_start": [],
     "capi_timer_stop_ms": [C.POINTER(C.c_float)],
     "capi_sync": [],

@@ -46,6 +46,8 @@ int capi_destroy(capi_handle_t h) {
   if (h->ws2) (void)hipFree(h->ws2);
   if (h->d_info) (void)hipFree(h->d_info);
   if (h->h_info) (void)hipHostFree(h->h_info);
+  for (int i = 0; i < h->prof_cap; ++i) if (h->prof[i].e0) { (void)hipEventDestroy(h->prof[i].e0); (void)hipEventDestroy(h->prof[i].e1); }
+  free(h->prof);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->owns_stream) (void)hipStreamDestroy(h->stream);

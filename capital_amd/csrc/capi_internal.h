@@ -21,6 +21,11 @@ struct capi_handle_s {
   int* h_info = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int num_cu = 256;
+  // per-launch HIP-event bracketing of the MFMA tile kernel (capi_prof_*): events live in a pool, results are summed on collect
+  bool prof_on = false;
+  struct prof_rec { hipEvent_t e0, e1; double flops; int variant; };
+  prof_rec* prof = nullptr;
+  int prof_n = 0, prof_cap = 0;
   char err[512] = {0};
 };
 

@@ -363,8 +363,27 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool allow_spli
   const size_t lds_bytes = sizeof(double) * 2 * STAGE_LDS;
   const int64_t nblk = (int64_t)p.ntiles * p.splitk;
   CAPI_REQUIRE(h, nblk < (int64_t)1 << 31, "too many tiles");
+  capi_handle_s::prof_rec* rec = nullptr;
+  if (h->prof_on) {
+    if (h->prof_n == h->prof_cap) {
+      const int ncap = h->prof_cap ? h->prof_cap * 2 : 1024;
+      auto* np_ = (capi_handle_s::prof_rec*)realloc(h->prof, sizeof(capi_handle_s::prof_rec) * ncap);
+      if (!np_) return CAPI_ENOMEM;
+      for (int i = h->prof_cap; i < ncap; ++i) { np_[i].e0 = nullptr; np_[i].e1 = nullptr; }
+      h->prof = np_;
+      h->prof_cap = ncap;
+    }
+    rec = &h->prof[h->prof_n++];
+    if (!rec->e0) { CAPI_HIP_CHECK(h, hipEventCreate(&rec->e0)); CAPI_HIP_CHECK(h, hipEventCreate(&rec->e1)); }
+    // algorithmic flops of this launch: gemm 2MNK, triangular output N(N+1)K, trmm M^2 N / M N^2
+    rec->flops = p.out_uplo >= 0 ? (double)p.N * ((double)p.N + 1.0) * (double)p.K
+                 : (p.tri_side >= 0 ? (double)p.M * (double)p.N * (double)p.K : 2.0 * (double)p.M * (double)p.N * (double)p.K);
+    rec->variant = (ak ? 2 : 0) + (bkc ? 1 : 0);
+    CAPI_HIP_CHECK(h, hipEventRecord(rec->e0, s));
+  }
   hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(NTHREADS), lds_bytes, s, p);
   CAPI_HIP_CHECK(h, hipGetLastError());
+  if (rec) CAPI_HIP_CHECK(h, hipEventRecord(rec->e1, s));
   if (p.splitk > 1) {
     dim3 grid((unsigned)cdiv(p.M, 256), (unsigned)(p.N < 65535 ? p.N : 65535));
     hipLaunchKernelGGL(splitk_reduce_kernel, grid, dim3(256), 0, s, p.slab, p.slab_ld, p.slab_stride, p.splitk, p.C, p.ldc,
@@ -485,6 +504,29 @@ int capi_dtrmm(capi_handle_t h, int side, int uplo, int trans, int diag, int64_t
   if (rc != CAPI_OK) return rc;
   CAPI_HIP_CHECK(h, hipMemcpy2DAsync(B, sizeof(double) * ldb, ws, sizeof(double) * m, sizeof(double) * m, n,
                                      hipMemcpyDeviceToDevice, h->stream));
+  return CAPI_OK;
+}
+
+int capi_prof_enable(capi_handle_t h, int on) {
+  CAPI_REQUIRE(h, h, "null handle");
+  h->prof_on = on != 0;
+  if (on) h->prof_n = 0;
+  return CAPI_OK;
+}
+
+// variant: 0 NN-like (row-contiguous A, row-contiguous B) .. 3 (k-contiguous A and B, the TN kernel of the trailing update); -1 all
+int capi_prof_collect(capi_handle_t h, int variant, int64_t* launches, double* total_ms, double* total_flops, double* max_ms) {
+  CAPI_REQUIRE(h, h && launches && total_ms && total_flops, "args");
+  CAPI_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+  *launches = 0; *total_ms = 0; *total_flops = 0;
+  if (max_ms) *max_ms = 0;
+  for (int i = 0; i < h->prof_n; ++i) {
+    if (variant >= 0 && h->prof[i].variant != variant) continue;
+    float ms = 0;
+    CAPI_HIP_CHECK(h, hipEventElapsedTime(&ms, h->prof[i].e0, h->prof[i].e1));
+    *launches += 1; *total_ms += ms; *total_flops += h->prof[i].flops;
+    if (max_ms && ms > *max_ms) *max_ms = ms;
+  }
   return CAPI_OK;
 }
 

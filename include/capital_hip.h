@@ -158,6 +158,11 @@ int capi_sendrecv_replace(capi_comm_t c, double* buf, int64_t count, int peer, d
 /* ---- measurement helpers ---- */
 /* register-resident v_mfma_f64_16x16x4_f64 loop on every CU: returns achieved TFLOP/s (synchronous) */
 int capi_mfma_f64_peak(capi_handle_t h, int iters, double* tflops);
+/* HIP-event bracket around EVERY launch of the MFMA tile kernel on the handle's stream (roofline measurement):
+ * enable, run the workload, collect = number of launches, summed duration and summed algorithmic flops of one
+ * kernel variant (3 = both operands k-contiguous, the TN kernel of the trailing update; -1 = all variants). */
+int capi_prof_enable(capi_handle_t h, int on);
+int capi_prof_collect(capi_handle_t h, int variant, int64_t* launches, double* total_ms, double* total_flops, double* max_ms);
 /* HIP-event timer on the handle's stream */
 int capi_timer_start(capi_handle_t h);
 int capi_timer_stop_ms(capi_handle_t h, float* ms);              /* synchronises */

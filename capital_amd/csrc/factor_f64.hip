@@ -3,7 +3,7 @@
 // Replaces LAPACKE_dpotrf / LAPACKE_dtrtri behind the reference's lapack::engine
 // (src/lapack/interface.hpp:30-58) and adds the block TRSM the reference lacks.
 //
-// Structure: one LDS-resident leaf kernel factors AND inverts a diagonal block of order <= 64 in a single
+// Structure: one register-resident leaf kernel factors AND inverts a diagonal block of order <= 128 in a single
 // launch (the reference's base case is exactly this pair: potrf, memcpy, trtri -- cholinv/policy.h:199-201,
 // cacqr.hpp:20-22); everything larger is the same recursion the reference runs across MPI ranks
 // (cholinv.hpp:87-165), executed here on one device with the MFMA tile kernel of gemm_f64.hip:
@@ -14,92 +14,183 @@ int capi_ws2_get(capi_handle_t h, size_t bytes, void** p);
 
 namespace {
 
-constexpr int LEAF = 64;
-constexpr int LDL = LEAF + 1;  // odd leading dimension: conflict-free ds_read_b64 along a row
+constexpr int LEAF = 128;
 
-// One workgroup.  A: b x b upper triangle in (lda); on exit A(upper) = R with A = R^T R, X(upper) = R^-1.
-// want_inv == 0 skips the inverse.  zero_lower: also write zeros below the diagonal of both outputs.
-// invert_only: A already holds a triangular R (skip the Cholesky sweep); unit: unit diagonal (invert_only)
-__global__ __launch_bounds__(256) void potrf_trtri_leaf_kernel(double* __restrict__ A, int64_t lda, double* __restrict__ X,
-                                                               int64_t ldx, int b, int want_inv, int zero_lower,
-                                                               int invert_only, int unit, int* __restrict__ info,
-                                                               int info_base) {
-  __shared__ double R[LEAF * LDL];
-  __shared__ double S[LEAF * LDL];
-  __shared__ double piv[LEAF];
+// One workgroup factors AND inverts a diagonal block of order b <= 16*E entirely in registers.
+// Thread (tx,ty) = (tid&15, tid>>4) owns the E x E elements (row tx+16a, col ty+16c): a wave covers 16 contiguous
+// rows of 4 columns (128-byte global accesses) and the cyclic ownership keeps every thread busy as the active
+// window shrinks.  Each step publishes ONE row (and for the inverse one column) through a double-buffered LDS
+// line, so there is exactly one barrier per step and no read-modify-write traffic in LDS:
+//   potrf, step j : everybody reads the current row j, R[r,c] -= R[j,r]*R[j,c]/p_j for j<r<=c in registers; the owners
+//                   of row j scale it by 1/sqrt(p_j); the owners of row j+1 publish it (already updated).
+//   trtri, step p : owners of row p turn S[p,:] into X[p,:] = (e_p - S[p,:])/R[p,p] and publish it, owners of column p
+//                   publish R[:,p]; everybody does S[j,c] += R[j,p]*X[p,c] for j<p<=c.
+// A(upper) -> R in place with A = R^T R; X(upper) <- R^-1.  want_inv == 0 skips the inverse; zero_lower also writes
+// zeros below the diagonal of both outputs; invert_only: A already holds a triangular R (unit: unit diagonal).
+template <int E>
+__global__ __launch_bounds__(256, 1) void potrf_trtri_leaf_kernel(double* __restrict__ A, int64_t lda, double* __restrict__ X,
+                                                                  int64_t ldx, int b, int want_inv, int zero_lower,
+                                                                  int invert_only, int unit, int* __restrict__ info,
+                                                                  int info_base) {
+  constexpr int NB = 16 * E;
+  __shared__ double rowbuf[2][NB];
+  __shared__ double colbuf[2][NB];
+  __shared__ double invd[NB];
   const int tid = threadIdx.x;
-  const int c = tid & 63, rg = tid >> 6;
+  const int tx = tid & 15, ty = tid >> 4;
+  double r[E][E], s[E][E];
 
-  // load upper triangle (coalesced along rows of a column)
-  for (int col = rg; col < b; col += 4) {
-    const int row = c;
-    if (row < b) {
-      double v = (row <= col) ? A[row + (int64_t)col * lda] : 0.0;
-      if (unit && row == col) v = 1.0;
-      R[row + col * LDL] = v;
-      S[row + col * LDL] = 0.0;
+#pragma unroll
+  for (int a = 0; a < E; ++a)
+#pragma unroll
+    for (int c = 0; c < E; ++c) {
+      const int row = tx + 16 * a, col = ty + 16 * c;
+      double v = 0.0;
+      if (row <= col && col < b) v = A[row + (int64_t)col * lda];
+      if (unit && row == col && col < b) v = 1.0;
+      r[a][c] = v;
+      s[a][c] = 0.0;
     }
+
+  // reciprocal diagonal of R, filled by the Cholesky sweep (or directly when R is given)
+  if (invert_only) {
+#pragma unroll
+    for (int a = 0; a < E; ++a)
+#pragma unroll
+      for (int c = 0; c < E; ++c)
+        if (tx + 16 * a == ty + 16 * c && tx + 16 * a < b) invd[tx + 16 * a] = 1.0 / r[a][c];
   }
-  __syncthreads();
 
   if (!invert_only) {
-    // right-looking Cholesky with ONE barrier per step.  Step j: (a) trailing update with the UNSCALED row j,
-    // R[r,c] -= R[j,r]*R[j,c]/p_j (j<r<=c); (b) scale the finished row j-1 by 1/sqrt(p_{j-1}).  Rows touched by
-    // (a) and (b) are disjoint.  Pivots are parked in piv[] and the diagonal is written once at the end.
+    if (tx == 0) {
+#pragma unroll
+      for (int c = 0; c < E; ++c) rowbuf[0][ty + 16 * c] = r[0][c];
+    }
+    __syncthreads();
     for (int j = 0; j < b; ++j) {
-      double p = R[j + j * LDL];
+      const int cur = j & 1, jb = j >> 4, jt = j & 15;
+      double p = rowbuf[cur][j];
       if (!(p > 0.0)) {
         if (tid == 0) atomicCAS(info, 0, info_base + j + 1);
         p = 1.0;
       }
-      if (tid == 0) piv[j] = p;
-      const double ip = 1.0 / p;
-      if (c > j && c < b) {
-        const double rjc = R[j + c * LDL] * ip;
-        for (int r = j + 1 + rg; r <= c; r += 4) R[r + c * LDL] -= R[j + r * LDL] * rjc;
+      // 1/sqrt(p), sqrt(p), 1/p from v_rsq_f64 + Newton (a few ulp; the IEEE sqrt/div sequences cost ~10x more per step)
+      double y = __builtin_amdgcn_rsq(p);
+      y = y * (1.5 - 0.5 * p * y * y);
+      y = y * (1.5 - 0.5 * p * y * y);
+      double sq = p * y;
+      sq = sq + 0.5 * y * (p - sq * sq);
+      double ip = y * y;
+      ip = ip * (2.0 - p * ip);
+      if (tid == 0) invd[j] = y;
+      double rc[E], rr[E];
+#pragma unroll
+      for (int c = 0; c < E; ++c) rc[c] = rowbuf[cur][ty + 16 * c] * ip;
+#pragma unroll
+      for (int a = 0; a < E; ++a) rr[a] = rowbuf[cur][tx + 16 * a];
+#pragma unroll
+      for (int a = 0; a < E; ++a) {
+        if (16 * a + 15 <= j) continue;                 // every row of this block is finished (uniform)
+        const int row = tx + 16 * a;
+#pragma unroll
+        for (int c = a; c < E; ++c) {                   // blocks below the diagonal never change
+          const int col = ty + 16 * c;
+          if (row > j && row <= col) r[a][c] -= rr[a] * rc[c];
+        }
       }
-      if (j > 0 && rg == 3 && c > j - 1 && c < b) R[(j - 1) + c * LDL] *= 1.0 / sqrt(piv[j - 1]);
+      if (tx == jt) {                                   // owners of row j: scale it, set the pivot
+#pragma unroll
+        for (int a = 0; a < E; ++a)
+          if (a == jb) {
+#pragma unroll
+            for (int c = a; c < E; ++c) {
+              const int col = ty + 16 * c;
+              r[a][c] = col > j ? r[a][c] * y : (col == j ? sq : r[a][c]);
+            }
+          }
+      }
+      // owners of row j+1 publish it (its trailing part was just updated by themselves)
+      const int jn = j + 1;
+      if (jn < b && tx == (jn & 15)) {
+#pragma unroll
+        for (int a = 0; a < E; ++a)
+          if (a == (jn >> 4)) {
+#pragma unroll
+            for (int c = 0; c < E; ++c) rowbuf[cur ^ 1][ty + 16 * c] = r[a][c];
+          }
+      }
       __syncthreads();
     }
-    if (rg == 0 && c < b) R[c + c * LDL] = sqrt(piv[c]);
+  } else {
     __syncthreads();
   }
 
   if (want_inv) {
-    // X = R^-1 by rows from the bottom: X[p,c] = (delta_pc - S[p,c]) / R[p,p], S[j,c] += R[j,p]*X[p,c] (j<p).
-    // One barrier per step: step p reads row p of S (complete), updates rows j<p; row p is finalised in place
-    // during step p-1 (nobody reads it then).
     for (int p = b - 1; p >= 0; --p) {
-      const double ipp = 1.0 / R[p + p * LDL];
-      if (c >= p && c < b) {
-        const double xpc = ((c == p ? 1.0 : 0.0) - S[p + c * LDL]) * ipp;
-        for (int j = rg; j < p; j += 4) S[j + c * LDL] += R[j + p * LDL] * xpc;
+      const int cur = p & 1, pb = p >> 4, pt = p & 15;
+      if (tx == pt) {                                   // owners of row p publish its partial sums
+#pragma unroll
+        for (int a = 0; a < E; ++a)
+          if (a == pb) {
+#pragma unroll
+            for (int c = 0; c < E; ++c) rowbuf[cur][ty + 16 * c] = s[a][c];
+          }
       }
-      if (p + 1 < b && rg == 0 && c >= p + 1 && c < b) {
-        const double iqq = 1.0 / R[(p + 1) + (p + 1) * LDL];
-        S[(p + 1) + c * LDL] = ((c == p + 1 ? 1.0 : 0.0) - S[(p + 1) + c * LDL]) * iqq;
+      if (ty == pt) {                                   // owners of column p publish R[:,p]
+#pragma unroll
+        for (int c = 0; c < E; ++c)
+          if (c == pb) {
+#pragma unroll
+            for (int a = 0; a < E; ++a) colbuf[cur][tx + 16 * a] = r[a][c];
+          }
       }
       __syncthreads();
+      const double ipp = invd[p];
+      double xr[E], rcol[E];
+#pragma unroll
+      for (int c = 0; c < E; ++c) {
+        const int col = ty + 16 * c;
+        xr[c] = col >= p && col < b ? ((col == p ? 1.0 : 0.0) - rowbuf[cur][col]) * ipp : 0.0;   // X[p,col]
+      }
+#pragma unroll
+      for (int a = 0; a < E; ++a) rcol[a] = colbuf[cur][tx + 16 * a];
+#pragma unroll
+      for (int a = 0; a < E; ++a) {
+        if (16 * a >= p) continue;                      // no row of this block lies above row p (uniform)
+        const int row = tx + 16 * a;
+#pragma unroll
+        for (int c = a; c < E; ++c) {
+          if (16 * c + 15 < p) continue;                // X[p, these columns] = 0 (uniform)
+          if (row < p) s[a][c] += rcol[a] * xr[c];
+        }
+      }
+      if (tx == pt) {
+#pragma unroll
+        for (int a = 0; a < E; ++a)
+          if (a == pb) {
+#pragma unroll
+            for (int c = 0; c < E; ++c) s[a][c] = xr[c];
+          }
+      }
+      // buffers of parity `cur` are rewritten two steps from now; the next step's barrier separates the uses
     }
-    if (b > 0 && rg == 0 && c < b) {
-      const double i00 = 1.0 / R[0];
-      S[0 + c * LDL] = ((c == 0 ? 1.0 : 0.0) - S[0 + c * LDL]) * i00;
-    }
-    __syncthreads();
   }
 
-  for (int col = rg; col < b; col += 4) {
-    const int row = c;
-    if (row < b) {
-      if (row <= col) {
-        if (!invert_only) A[row + (int64_t)col * lda] = R[row + col * LDL];
-        if (want_inv) X[row + (int64_t)col * ldx] = S[row + col * LDL];
-      } else if (zero_lower) {
-        if (!invert_only) A[row + (int64_t)col * lda] = 0.0;
-        if (want_inv) X[row + (int64_t)col * ldx] = 0.0;
+#pragma unroll
+  for (int a = 0; a < E; ++a)
+#pragma unroll
+    for (int c = 0; c < E; ++c) {
+      const int row = tx + 16 * a, col = ty + 16 * c;
+      if (row < b && col < b) {
+        if (row <= col) {
+          if (!invert_only) A[row + (int64_t)col * lda] = r[a][c];
+          if (want_inv) X[row + (int64_t)col * ldx] = s[a][c];
+        } else if (zero_lower) {
+          if (!invert_only) A[row + (int64_t)col * lda] = 0.0;
+          if (want_inv) X[row + (int64_t)col * ldx] = 0.0;
+        }
       }
     }
-  }
 }
 
 __global__ void scale2d_kernel(double* __restrict__ B, int64_t ldb, int64_t m, int64_t n, double alpha) {
@@ -117,8 +208,12 @@ int64_t split_point(int64_t n) {
 
 int leaf_launch(capi_handle_t h, double* A, int64_t lda, double* X, int64_t ldx, int b, int want_inv, int zero_lower,
                 int invert_only, int unit, int info_base) {
-  hipLaunchKernelGGL(potrf_trtri_leaf_kernel, dim3(1), dim3(256), 0, h->stream, A, lda, X, ldx, b, want_inv, zero_lower,
-                     invert_only, unit, h->d_info, info_base);
+  if (b <= 64)
+    hipLaunchKernelGGL(potrf_trtri_leaf_kernel<4>, dim3(1), dim3(256), 0, h->stream, A, lda, X, ldx, b, want_inv, zero_lower,
+                       invert_only, unit, h->d_info, info_base);
+  else
+    hipLaunchKernelGGL(potrf_trtri_leaf_kernel<8>, dim3(1), dim3(256), 0, h->stream, A, lda, X, ldx, b, want_inv, zero_lower,
+                       invert_only, unit, h->d_info, info_base);
   CAPI_HIP_CHECK(h, hipGetLastError());
   return CAPI_OK;
 }

@@ -25,11 +25,17 @@ typedef double d2_t __attribute__((ext_vector_type(2)));
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 16, NTHREADS = 256;
+constexpr int BK = 16, NTHREADS = 256;
 constexpr int SK = BK + 2;            // [row][k] layout: row stride in doubles (144 B, 16-B aligned, odd multiple of 16 B)
-constexpr int SR = 128 + 8;           // [k][row] layout: k-row stride in doubles (1088 B)
-constexpr int TILE_LDS = 128 * SK;    // 2304 doubles >= BK*SR = 2176
-constexpr int STAGE_LDS = 2 * TILE_LDS;
+// Two tile sizes share the code: TS = 128 (4x4 MFMA tiles per wave) for large outputs, TS = 64 (2x2 per wave, 4
+// workgroups per CU) when a 128-tiling would leave CUs idle (the small levels of the recursion).
+template <int TS> struct tile_cfg {
+  static constexpr int SR = TS + 8;                 // [k][row] layout: k-row stride in doubles
+  static constexpr int TILE_LDS = TS * SK;          // >= BK*SR
+  static constexpr int STAGE_LDS = 2 * TILE_LDS;
+  static constexpr int NQ = TS / 32;                // 16-byte pieces per thread per operand panel
+  static constexpr int SUB = TS / 32;               // MFMA tiles per wave per dimension
+};
 constexpr int GROUP_M = 8;
 
 struct GemmArgs {
@@ -48,17 +54,19 @@ struct GemmArgs {
   double* slab;       // split-K partial sums: slab[z*slab_stride + i + j*slab_ld]
   int64_t slab_ld, slab_stride;
   int tiles_m, tiles_n, ntiles;
+  int ts;             // tile size chosen by the launcher
 };
 
 // ---- global -> registers: this thread's 4 x 16 bytes of a 128 x 16 operand panel -----------------
-template <bool KC>
+template <int TS, bool KC>
 __device__ __forceinline__ void panel_load(const double* __restrict__ X, int64_t ld, int r0, int R, int k0, int kend,
-                                           int tid, bool vec_ok, d2_t (&v)[4]) {
+                                           int tid, bool vec_ok, d2_t (&v)[TS / 32]) {
+  constexpr int NQ = TS / 32;
   if (KC) {  // element (r,k) at X[k + r*ld]
     const int kp = tid & 7, rb = tid >> 3;
     const int k = k0 + 2 * kp;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NQ; ++q) {
       const int r = r0 + rb + 32 * q;
       d2_t val = {0.0, 0.0};
       if (r < R) {
@@ -73,11 +81,11 @@ __device__ __forceinline__ void panel_load(const double* __restrict__ X, int64_t
       v[q] = val;
     }
   } else {  // element (r,k) at X[r + k*ld]
-    const int rp = tid & 63, kb = tid >> 6;
+    const int rp = tid & (TS / 2 - 1), kb = tid / (TS / 2);
     const int r = r0 + 2 * rp;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int k = k0 + kb + 4 * q;
+    for (int q = 0; q < NQ; ++q) {
+      const int k = k0 + kb + (512 / TS) * q;
       d2_t val = {0.0, 0.0};
       if (k < kend) {
         const double* p = X + (int64_t)k * ld + r;
@@ -95,19 +103,19 @@ __device__ __forceinline__ void panel_load(const double* __restrict__ X, int64_t
 
 // zero what lies outside the triangle of op(T) (and force a unit diagonal) on a staged panel.
 // keep_ge: keep k >= r, else keep k <= r  (r = the panel's row index in op(T) coordinates)
-template <bool KC>
-__device__ __forceinline__ void panel_mask(int r0, int k0, int tid, bool keep_ge, bool unit, d2_t (&v)[4]) {
+template <int TS, bool KC>
+__device__ __forceinline__ void panel_mask(int r0, int k0, int tid, bool keep_ge, bool unit, d2_t (&v)[TS / 32]) {
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < TS / 32; ++q) {
     int r[2], k[2];
     if (KC) {
       r[0] = r[1] = r0 + (tid >> 3) + 32 * q;
       k[0] = k0 + 2 * (tid & 7);
       k[1] = k[0] + 1;
     } else {
-      r[0] = r0 + 2 * (tid & 63);
+      r[0] = r0 + 2 * (tid & (TS / 2 - 1));
       r[1] = r[0] + 1;
-      k[0] = k[1] = k0 + (tid >> 6) + 4 * q;
+      k[0] = k[1] = k0 + tid / (TS / 2) + (512 / TS) * q;
     }
     double e0 = v[q].x, e1 = v[q].y;
     if (keep_ge ? (k[0] < r[0]) : (k[0] > r[0])) e0 = 0.0;
@@ -121,23 +129,25 @@ __device__ __forceinline__ void panel_mask(int r0, int k0, int tid, bool keep_ge
   }
 }
 
-template <bool KC>
-__device__ __forceinline__ void panel_store(double* __restrict__ L, int tid, const d2_t (&v)[4]) {
+template <int TS, bool KC>
+__device__ __forceinline__ void panel_store(double* __restrict__ L, int tid, const d2_t (&v)[TS / 32]) {
+  constexpr int SR = tile_cfg<TS>::SR;
   if (KC) {
     const int kp = tid & 7, rb = tid >> 3;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) *(d2_t*)&L[(rb + 32 * q) * SK + 2 * kp] = v[q];
+    for (int q = 0; q < TS / 32; ++q) *(d2_t*)&L[(rb + 32 * q) * SK + 2 * kp] = v[q];
   } else {
-    const int rp = tid & 63, kb = tid >> 6;
+    const int rp = tid & (TS / 2 - 1), kb = tid / (TS / 2);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) *(d2_t*)&L[(kb + 4 * q) * SR + 2 * rp] = v[q];
+    for (int q = 0; q < TS / 32; ++q) *(d2_t*)&L[(kb + (512 / TS) * q) * SR + 2 * rp] = v[q];
   }
 }
 
 // fragment for MFMA k-steps 2u and 2u+1 of 16-row sub-block `row` (panel row index of this lane).
 // k-step s = 2u+e of lane group g = lane>>4 consumes physical k = 8u + 2g + e in BOTH operands.
-template <bool KC>
+template <int TS, bool KC>
 __device__ __forceinline__ d2_t frag_read(const double* __restrict__ L, int row, int u, int g) {
+  constexpr int SR = tile_cfg<TS>::SR;
   if (KC) {
     return *(const d2_t*)&L[row * SK + 8 * u + 2 * g];
   } else {
@@ -172,8 +182,10 @@ __device__ __forceinline__ void tile_of(const GemmArgs& p, int t, int& ti, int& 
   }
 }
 
-template <bool AK, bool BKC>
-__global__ __launch_bounds__(NTHREADS, 2) void dgemm_tile_kernel(const GemmArgs p) {
+template <int TS, bool AK, bool BKC>
+__global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel(const GemmArgs p) {
+  constexpr int BM = TS, BN = TS, SUB = tile_cfg<TS>::SUB, NQ = tile_cfg<TS>::NQ;
+  constexpr int TILE_LDS = tile_cfg<TS>::TILE_LDS, STAGE_LDS = tile_cfg<TS>::STAGE_LDS;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -204,20 +216,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void dgemm_tile_kernel(const GemmArgs 
   const bool maskA = p.tri_side == CAPI_LEFT, maskB = p.tri_side == CAPI_RIGHT;
   const bool keep_ge = (p.tri_side == CAPI_LEFT) == (p.tri_eff_upper != 0);
 
-  d4_t acc[4][4];
+  d4_t acc[SUB][SUB];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < SUB; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = (d4_t){0.0, 0.0, 0.0, 0.0};
+    for (int b = 0; b < SUB; ++b) acc[a][b] = (d4_t){0.0, 0.0, 0.0, 0.0};
 
-  d2_t ra[4], rb[4];
+  d2_t ra[NQ], rb[NQ];
   if (ntk > 0) {
-    panel_load<AK>(p.A, p.lda, i0, p.M, klo, khi, tid, p.a_vec, ra);
-    panel_load<BKC>(p.B, p.ldb, j0, p.N, klo, khi, tid, p.b_vec, rb);
-    if (maskA && klo < i0 + BM && klo + BK > i0) panel_mask<AK>(i0, klo, tid, keep_ge, p.tri_unit, ra);
-    if (maskB && klo < j0 + BN && klo + BK > j0) panel_mask<BKC>(j0, klo, tid, keep_ge, p.tri_unit, rb);
-    panel_store<AK>(lds, tid, ra);
-    panel_store<BKC>(lds + TILE_LDS, tid, rb);
+    panel_load<TS, AK>(p.A, p.lda, i0, p.M, klo, khi, tid, p.a_vec, ra);
+    panel_load<TS, BKC>(p.B, p.ldb, j0, p.N, klo, khi, tid, p.b_vec, rb);
+    if (maskA && klo < i0 + BM && klo + BK > i0) panel_mask<TS, AK>(i0, klo, tid, keep_ge, p.tri_unit, ra);
+    if (maskB && klo < j0 + BN && klo + BK > j0) panel_mask<TS, BKC>(j0, klo, tid, keep_ge, p.tri_unit, rb);
+    panel_store<TS, AK>(lds, tid, ra);
+    panel_store<TS, BKC>(lds + TILE_LDS, tid, rb);
   }
   __syncthreads();
 
@@ -227,33 +239,33 @@ __global__ __launch_bounds__(NTHREADS, 2) void dgemm_tile_kernel(const GemmArgs 
     const int kn = klo + (t + 1) * BK;
     const bool more = (t + 1 < ntk);
     if (more) {
-      panel_load<AK>(p.A, p.lda, i0, p.M, kn, khi, tid, p.a_vec, ra);
-      panel_load<BKC>(p.B, p.ldb, j0, p.N, kn, khi, tid, p.b_vec, rb);
+      panel_load<TS, AK>(p.A, p.lda, i0, p.M, kn, khi, tid, p.a_vec, ra);
+      panel_load<TS, BKC>(p.B, p.ldb, j0, p.N, kn, khi, tid, p.b_vec, rb);
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      d2_t af[4], bf[4];
+      d2_t af[SUB], bf[SUB];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) af[a] = frag_read<AK>(La, wm * 64 + a * 16 + r16, u, g);
+      for (int a = 0; a < SUB; ++a) af[a] = frag_read<TS, AK>(La, wm * (TS / 2) + a * 16 + r16, u, g);
 #pragma unroll
-      for (int b = 0; b < 4; ++b) bf[b] = frag_read<BKC>(Lb, wn * 64 + b * 16 + r16, u, g);
+      for (int b = 0; b < SUB; ++b) bf[b] = frag_read<TS, BKC>(Lb, wn * (TS / 2) + b * 16 + r16, u, g);
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+      for (int a = 0; a < SUB; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < SUB; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].x, af[a].x, acc[a][b], 0, 0, 0);
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+      for (int a = 0; a < SUB; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < SUB; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].y, af[a].y, acc[a][b], 0, 0, 0);
     }
     if (more) {
-      if (maskA && kn < i0 + BM && kn + BK > i0) panel_mask<AK>(i0, kn, tid, keep_ge, p.tri_unit, ra);
-      if (maskB && kn < j0 + BN && kn + BK > j0) panel_mask<BKC>(j0, kn, tid, keep_ge, p.tri_unit, rb);
+      if (maskA && kn < i0 + BM && kn + BK > i0) panel_mask<TS, AK>(i0, kn, tid, keep_ge, p.tri_unit, ra);
+      if (maskB && kn < j0 + BN && kn + BK > j0) panel_mask<TS, BKC>(j0, kn, tid, keep_ge, p.tri_unit, rb);
       double* Na = lds + ((t + 1) & 1) * STAGE_LDS;
-      panel_store<AK>(Na, tid, ra);
-      panel_store<BKC>(Na + TILE_LDS, tid, rb);
+      panel_store<TS, AK>(Na, tid, ra);
+      panel_store<TS, BKC>(Na + TILE_LDS, tid, rb);
     }
     __syncthreads();
   }
@@ -261,13 +273,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void dgemm_tile_kernel(const GemmArgs 
   // epilogue: lane holds C[i = ..+r16][j = ..+g+4*reg]; 16 lanes -> 128 contiguous bytes of one column
   const bool to_slab = p.splitk > 1;
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const int i = i0 + wm * 64 + a * 16 + r16;
+  for (int a = 0; a < SUB; ++a) {
+    const int i = i0 + wm * (TS / 2) + a * 16 + r16;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
+    for (int b = 0; b < SUB; ++b) {
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
-        const int j = j0 + wn * 64 + b * 16 + g + 4 * reg;
+        const int j = j0 + wn * (TS / 2) + b * 16 + g + 4 * reg;
         bool ok = (i < p.M) && (j < p.N);
         if (p.out_uplo == CAPI_UPPER) ok = ok && (i <= j);
         if (p.out_uplo == CAPI_LOWER) ok = ok && (i >= j);
@@ -318,7 +330,20 @@ __global__ void scale_kernel(double* __restrict__ C, int64_t ldc, int M, int N, 
 
 typedef void (*gemm_kernel_t)(const GemmArgs);
 
-int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool allow_splitk) {
+template <int TS>
+gemm_kernel_t pick_kernel(bool ak, bool bkc) {
+  return ak ? (bkc ? dgemm_tile_kernel<TS, true, true> : dgemm_tile_kernel<TS, true, false>)
+            : (bkc ? dgemm_tile_kernel<TS, false, true> : dgemm_tile_kernel<TS, false, false>);
+}
+
+int64_t count_tiles(const GemmArgs& p, int ts) {
+  const int64_t tm = cdiv(p.M, ts), tn = cdiv(p.N, ts);
+  return p.out_uplo < 0 ? tm * tn : tm * (tm + 1) / 2;
+}
+
+// ws_for_slab: split-K partials go to the handle's primary workspace; callers that already stage through it
+// (in-place trmm) pass false.
+int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_slab) {
   if (p.M <= 0 || p.N <= 0) return CAPI_OK;
   hipStream_t s = h->stream;
   if (p.K <= 0 || p.alpha == 0.0) {
@@ -328,39 +353,41 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool allow_spli
     CAPI_HIP_CHECK(h, hipGetLastError());
     return CAPI_OK;
   }
-  p.tiles_m = (int)cdiv(p.M, BM);
-  p.tiles_n = (int)cdiv(p.N, BN);
-  p.ntiles = p.out_uplo < 0 ? p.tiles_m * p.tiles_n : (int)((int64_t)p.tiles_m * (p.tiles_m + 1) / 2);
+  // tile size: 128 when that alone fills the chip twice over (2 workgroups per CU), else 64
+  const int64_t slots = 2 * (int64_t)h->num_cu;
+  p.ts = count_tiles(p, 128) >= slots ? 128 : 64;
+  p.tiles_m = (int)cdiv(p.M, p.ts);
+  p.tiles_n = (int)cdiv(p.N, p.ts);
+  p.ntiles = (int)count_tiles(p, p.ts);
   p.a_vec = (((uintptr_t)p.A & 15) == 0) && ((p.lda & 1) == 0);
   p.b_vec = (((uintptr_t)p.B & 15) == 0) && ((p.ldb & 1) == 0);
   p.splitk = 1;
   p.k_per_split = p.K;
   p.slab = nullptr;
   p.slab_ld = p.slab_stride = 0;
-  // split-K only for small outputs with a long K (CholeskyQR2 Gram matrices)
-  const int target = 4 * h->num_cu;
-  if (allow_splitk && p.tri_side < 0 && p.ntiles * 2 <= target && p.K >= 4096) {
-    int sk = target / p.ntiles;
-    int max_sk = p.K / 512;  // at least 512-deep slices
-    sk = sk < max_sk ? sk : max_sk;
+  // split-K when even the small tiling leaves CUs idle: tall-skinny Gram matrices (K = m_loc >> n) and the
+  // small levels of the recursion.  Slices are at least 128 deep and the grid is filled about twice.
+  if (ws_for_slab && p.ntiles < slots && p.K >= 512) {
+    int64_t sk = cdiv(2 * slots, p.ntiles);
+    const int64_t max_sk = p.K / 128;
+    if (sk > max_sk) sk = max_sk;
     if (sk > 1) {
-      int kps = (int)cdiv(cdiv(p.K, sk), BK) * BK;
-      sk = (int)cdiv(p.K, kps);
+      const int64_t kps = cdiv(cdiv(p.K, sk), BK) * BK;
+      sk = cdiv(p.K, kps);
       if (sk > 1) {
-        p.splitk = sk;
-        p.k_per_split = kps;
+        p.splitk = (int)sk;
+        p.k_per_split = (int)kps;
         p.slab_ld = p.M;
         p.slab_stride = (int64_t)p.M * p.N;
         void* ws;
-        int rc = capi_ws_get(h, sizeof(double) * (size_t)p.slab_stride * sk, &ws);
+        int rc = capi_ws_get(h, sizeof(double) * (size_t)p.slab_stride * (size_t)sk, &ws);
         if (rc != CAPI_OK) return rc;
         p.slab = (double*)ws;
       }
     }
   }
-  gemm_kernel_t k = ak ? (bkc ? dgemm_tile_kernel<true, true> : dgemm_tile_kernel<true, false>)
-                       : (bkc ? dgemm_tile_kernel<false, true> : dgemm_tile_kernel<false, false>);
-  const size_t lds_bytes = sizeof(double) * 2 * STAGE_LDS;
+  gemm_kernel_t k = p.ts == 128 ? pick_kernel<128>(ak, bkc) : pick_kernel<64>(ak, bkc);
+  const size_t lds_bytes = sizeof(double) * 2 * (p.ts == 128 ? tile_cfg<128>::STAGE_LDS : tile_cfg<64>::STAGE_LDS);
   const int64_t nblk = (int64_t)p.ntiles * p.splitk;
   CAPI_REQUIRE(h, nblk < (int64_t)1 << 31, "too many tiles");
   capi_handle_s::prof_rec* rec = nullptr;
@@ -378,7 +405,7 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool allow_spli
     // algorithmic flops of this launch: gemm 2MNK, triangular output N(N+1)K, trmm M^2 N / M N^2
     rec->flops = p.out_uplo >= 0 ? (double)p.N * ((double)p.N + 1.0) * (double)p.K
                  : (p.tri_side >= 0 ? (double)p.M * (double)p.N * (double)p.K : 2.0 * (double)p.M * (double)p.N * (double)p.K);
-    rec->variant = (ak ? 2 : 0) + (bkc ? 1 : 0);
+    rec->variant = (ak ? 2 : 0) + (bkc ? 1 : 0) + (p.ts == 128 ? 0 : 4);
     CAPI_HIP_CHECK(h, hipEventRecord(rec->e0, s));
   }
   hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(NTHREADS), lds_bytes, s, p);
@@ -460,7 +487,8 @@ int capi_dsyrk(capi_handle_t h, int uplo, int trans, int64_t n, int64_t k, doubl
 }
 
 static int trmm_launch(capi_handle_t h, int side, int uplo, int trans, int diag, int64_t m, int64_t n, double alpha,
-                       const double* T, int64_t ldt, const double* B, int64_t ldb, double beta, double* C, int64_t ldc) {
+                       const double* T, int64_t ldt, const double* B, int64_t ldb, double beta, double* C, int64_t ldc,
+                       bool ws_free = true) {
   CAPI_REQUIRE(h, h, "null handle");
   CAPI_REQUIRE(h, ok01(side) && ok01(uplo) && ok01(trans) && ok01(diag), "enum code");
   CAPI_REQUIRE(h, m >= 0 && n >= 0 && m < (1LL << 31) && n < (1LL << 31), "dims");
@@ -476,10 +504,10 @@ static int trmm_launch(capi_handle_t h, int side, int uplo, int trans, int diag,
   p.tri_unit = diag == CAPI_UNIT;
   if (side == CAPI_LEFT) {  // C = alpha op(T) B : A-operand = T (transA = trans), B-operand = B (NoTrans)
     p.A = T; p.lda = ldt; p.B = B; p.ldb = ldb;
-    return launch_gemm(h, trans == CAPI_TRANS, true, p, false);
+    return launch_gemm(h, trans == CAPI_TRANS, true, p, ws_free);
   } else {                  // C = alpha B op(T) : A-operand = B (NoTrans), B-operand = T (transB = trans)
     p.A = B; p.lda = ldb; p.B = T; p.ldb = ldt;
-    return launch_gemm(h, false, trans == CAPI_NOTRANS, p, false);
+    return launch_gemm(h, false, trans == CAPI_NOTRANS, p, ws_free);
   }
 }
 
@@ -500,7 +528,7 @@ int capi_dtrmm(capi_handle_t h, int side, int uplo, int trans, int diag, int64_t
   void* ws;
   int rc = capi_ws_get(h, sizeof(double) * (size_t)m * (size_t)n, &ws);
   if (rc != CAPI_OK) return rc;
-  rc = capi_dtrmm_oop(h, side, uplo, trans, diag, m, n, alpha, T, ldt, B, ldb, (double*)ws, m);
+  rc = trmm_launch(h, side, uplo, trans, diag, m, n, alpha, T, ldt, B, ldb, 0.0, (double*)ws, m, /*ws_free=*/false);
   if (rc != CAPI_OK) return rc;
   CAPI_HIP_CHECK(h, hipMemcpy2DAsync(B, sizeof(double) * ldb, ws, sizeof(double) * m, sizeof(double) * m, n,
                                      hipMemcpyDeviceToDevice, h->stream));
@@ -521,7 +549,7 @@ int capi_prof_collect(capi_handle_t h, int variant, int64_t* launches, double* t
   *launches = 0; *total_ms = 0; *total_flops = 0;
   if (max_ms) *max_ms = 0;
   for (int i = 0; i < h->prof_n; ++i) {
-    if (variant >= 0 && h->prof[i].variant != variant) continue;
+    if (variant >= 0 && (h->prof[i].variant & 3) != variant) continue;
     float ms = 0;
     CAPI_HIP_CHECK(h, hipEventElapsedTime(&ms, h->prof[i].e0, h->prof[i].e1));
     *launches += 1; *total_ms += ms; *total_flops += h->prof[i].flops;

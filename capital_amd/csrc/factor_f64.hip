@@ -193,6 +193,205 @@ __global__ __launch_bounds__(256, 1) void potrf_trtri_leaf_kernel(double* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// MFMA-blocked leaf: one workgroup factors AND inverts a diagonal block of order b <= 128 held in LDS (128 x 130 doubles,
+// leading dimension 130 = 2 mod 32 -> conflict-free ds_read_b64 fragment reads).  Panels are 16 wide (the fp64 MFMA tile):
+//   diag(k)     16 fused steps on the 16x16 diagonal tile, one element per thread, one barrier per step: the right-looking
+//               Cholesky update AND the forward substitution for V = U^-T run together (both need only row s of U);
+//   panel(k)    R_kc = V * A_kc          for the tiles right of the diagonal        (MFMA, tiles dealt to the 4 waves)
+//   trailing(k) A_rc -= R_kr^T * R_kc    for k < r <= c                              (MFMA)
+// then the inverse, block column by block column, in place over the factor (which has already gone to HBM):
+//   W_k = R_kj * X_jj (k < j),  X_ij = -sum_{k=i..j-1} X_ik W_k  (products in registers, barrier, then written),  X_jj = V_j^T.
+// The 16-step diagonal phases are the critical path (~250 cycles a step); everything else is a few hundred MFMAs.
+typedef double d4l_t __attribute__((ext_vector_type(4)));
+constexpr int LB = 128, LLD = 130, LNT = 8;
+
+__device__ __forceinline__ void leaf_diag(double* __restrict__ M, double* __restrict__ Vs, double (*rowU)[16], double (*rowW)[16],
+                                          int k, int tid, bool given, bool unit, int* __restrict__ info, int info_base, int b) {
+  const int i = tid & 15, j = tid >> 4, k0 = 16 * k;
+  double a = M[(k0 + i) + (k0 + j) * LLD];
+  if (i > j) a = 0.0;
+  if (given && unit && i == j) a = 1.0;
+  double w = 0.0;                       // accumulates sum_m U[m][i] V[m][j], becomes V[i][j] (j <= i)
+  if (i == 0) { rowU[0][j] = a; rowW[0][j] = 0.0; }
+  __syncthreads();
+  for (int s = 0; s < 16; ++s) {
+    const int cur = s & 1;
+    double p = rowU[cur][s];
+    double y, sq;
+    if (given) {
+      if (p == 0.0) p = 1.0;
+      y = 1.0 / p;                      // row s of U is final: y = 1/u_ss
+      sq = p;
+    } else {
+      if (!(p > 0.0)) {
+        if (tid == 0 && k0 + s < b) atomicCAS(info, 0, info_base + k0 + s + 1);
+        p = 1.0;
+      }
+      y = __builtin_amdgcn_rsq(p);
+      y = y * (1.5 - 0.5 * p * y * y);
+      y = y * (1.5 - 0.5 * p * y * y);
+      sq = p * y;
+      sq = sq + 0.5 * y * (p - sq * sq);
+    }
+    const double ui = rowU[cur][i], uj = rowU[cur][j];
+    const double vsj = j <= s ? ((j == s ? 1.0 : 0.0) - rowW[cur][j]) * y : 0.0;     // V[s][j]
+    const double usi = given ? ui : ui * y;                                           // U[s][i]
+    if (i > s) {
+      if (!given && i <= j) a -= ui * uj * (y * y);
+      w += usi * vsj;
+    } else if (i == s) {
+      if (!given) a = j > s ? uj * y : (j == s ? sq : 0.0);
+      w = vsj;
+    }
+    if (s + 1 < 16 && i == s + 1) { rowU[cur ^ 1][j] = a; rowW[cur ^ 1][j] = w; }
+    __syncthreads();
+  }
+  M[(k0 + i) + (k0 + j) * LLD] = i <= j ? a : 0.0;
+  Vs[k * 256 + i + j * 16] = j <= i ? w : 0.0;          // V[i][j], stored [col][row]-major with ld 16
+}
+
+__global__ __launch_bounds__(256, 1) void potrf_trtri_leaf128_kernel(double* __restrict__ A, int64_t lda, double* __restrict__ X,
+                                                                      int64_t ldx, int b, int want_inv, int zero_lower,
+                                                                      int invert_only, int unit, int* __restrict__ info,
+                                                                      int info_base) {
+  extern __shared__ __attribute__((aligned(16))) double lds_leaf[];
+  double* M = lds_leaf;                       // LB x LLD
+  double* Vs = M + LB * LLD;                  // LNT tiles of 16 x 16
+  double(*rowU)[16] = (double(*)[16])(Vs + LNT * 256);
+  double(*rowW)[16] = rowU + 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int nk = (b + 15) >> 4;               // active 16-wide panels
+
+  // load (upper triangle; identity padding beyond b keeps the padded problem SPD)
+  for (int col = tid >> 7; col < 16 * nk; col += 2) {
+    const int row = tid & 127;
+    if (row < 16 * nk) {
+      double v = 0.0;
+      if (row < b && col < b) { if (row <= col) v = A[row + (int64_t)col * lda]; }
+      else if (row == col) v = 1.0;
+      M[row + col * LLD] = v;
+    }
+  }
+  __syncthreads();
+
+  for (int k = 0; k < nk; ++k) {
+    leaf_diag(M, Vs, rowU, rowW, k, tid, invert_only != 0, unit != 0, info, info_base, b);
+    __syncthreads();
+    if (invert_only || k + 1 >= nk) continue;
+    const int k0 = 16 * k;
+    // panel: R_kc = V_k * A_kc
+    for (int c = k + 1 + wave; c < nk; c += 4) {
+      const int c0 = 16 * c;
+      d4l_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        const int m = 4 * st + g;
+        const double av = Vs[k * 256 + r16 + m * 16];                 // V[i=r16][m]
+        const double bv = M[(k0 + m) + (c0 + r16) * LLD];             // A_kc[m][j=r16]
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) M[(k0 + g + 4 * q) + (c0 + r16) * LLD] = acc[q];
+    }
+    __syncthreads();
+    // trailing: A_rc -= R_kr^T R_kc, k < r <= c
+    const int nt = nk - 1 - k, ntiles = nt * (nt + 1) / 2;
+    for (int t = wave; t < ntiles; t += 4) {
+      int hi = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+      while (hi * (hi + 1) / 2 > t) --hi;
+      while ((hi + 1) * (hi + 2) / 2 <= t) ++hi;
+      const int lo = t - hi * (hi + 1) / 2;
+      const int r0 = 16 * (k + 1 + lo), c0 = 16 * (k + 1 + hi);
+      d4l_t acc;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = M[(r0 + g + 4 * q) + (c0 + r16) * LLD];
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        const int m = 4 * st + g;
+        const double av = -M[(k0 + m) + (r0 + r16) * LLD];            // -R_kr[m][i=r16]
+        const double bv = M[(k0 + m) + (c0 + r16) * LLD];             //  R_kc[m][j=r16]
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) M[(r0 + g + 4 * q) + (c0 + r16) * LLD] = acc[q];
+    }
+    __syncthreads();
+  }
+
+  if (!invert_only) {
+    for (int col = tid >> 7; col < b; col += 2) {
+      const int row = tid & 127;
+      if (row < b) {
+        if (row <= col) A[row + (int64_t)col * lda] = M[row + col * LLD];
+        else if (zero_lower) A[row + (int64_t)col * lda] = 0.0;
+      }
+    }
+  }
+
+  if (want_inv) {
+    for (int j = 0; j < nk; ++j) {
+      const int j0 = 16 * j;
+      // phase A: W_k = R_kj * X_jj for k < j (in place over tile (k,j)); X_jj[m][q] = V_j[q][m]
+      for (int k = wave; k < j; k += 4) {
+        const int k0 = 16 * k;
+        d4l_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+          const int m = 4 * st + g;
+          const double av = M[(k0 + r16) + (j0 + m) * LLD];           // R_kj[i=r16][m]
+          const double bv = Vs[j * 256 + r16 + m * 16];               // X_jj[m][q=r16] = V_j[q][m]
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+        // all four fragment loads of this tile were consumed by the MFMAs above before the stores below (same wave)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) M[(k0 + g + 4 * q) + (j0 + r16) * LLD] = acc[q];
+      }
+      __syncthreads();
+      // phase B: X_ij = -sum_{k=i}^{j-1} X_ik W_k for i < j; each wave keeps its (at most two) tiles in registers
+      d4l_t out[2];
+      int ni = 0;
+      for (int i = wave; i < j; i += 4, ++ni) {
+        const int i0 = 16 * i;
+        d4l_t acc = {0.0, 0.0, 0.0, 0.0};
+        for (int k = i; k < j; ++k) {
+          const int k0 = 16 * k;
+#pragma unroll
+          for (int st = 0; st < 4; ++st) {
+            const int m = 4 * st + g;
+            const double av = -M[(i0 + r16) + (k0 + m) * LLD];        // -X_ik[i=r16][m]
+            const double bv = M[(k0 + m) + (j0 + r16) * LLD];         //  W_k[m][q=r16]
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+          }
+        }
+        if (ni == 0) out[0] = acc; else out[1] = acc;
+      }
+      __syncthreads();
+      ni = 0;
+      for (int i = wave; i < j; i += 4, ++ni) {
+        const int i0 = 16 * i;
+        const d4l_t acc = ni == 0 ? out[0] : out[1];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) M[(i0 + g + 4 * q) + (j0 + r16) * LLD] = acc[q];
+      }
+      // X_jj = V_j^T into the diagonal tile
+      {
+        const int i = tid & 15, q = tid >> 4;
+        M[(j0 + i) + (j0 + q) * LLD] = i <= q ? Vs[j * 256 + q + i * 16] : 0.0;   // X[i][q] = V[q][i]
+      }
+      __syncthreads();
+    }
+    for (int col = tid >> 7; col < b; col += 2) {
+      const int row = tid & 127;
+      if (row < b) {
+        if (row <= col) X[row + (int64_t)col * ldx] = M[row + col * LLD];
+        else if (zero_lower) X[row + (int64_t)col * ldx] = 0.0;
+      }
+    }
+  }
+}
+
 __global__ void scale2d_kernel(double* __restrict__ B, int64_t ldb, int64_t m, int64_t n, double alpha) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
@@ -208,12 +407,16 @@ int64_t split_point(int64_t n) {
 
 int leaf_launch(capi_handle_t h, double* A, int64_t lda, double* X, int64_t ldx, int b, int want_inv, int zero_lower,
                 int invert_only, int unit, int info_base) {
-  if (b <= 64)
-    hipLaunchKernelGGL(potrf_trtri_leaf_kernel<4>, dim3(1), dim3(256), 0, h->stream, A, lda, X, ldx, b, want_inv, zero_lower,
+  {
+    const size_t lds_bytes = sizeof(double) * (LB * LLD + LNT * 256 + 4 * 16);
+    static bool attr_set = false;
+    if (!attr_set) {
+      CAPI_HIP_CHECK(h, hipFuncSetAttribute((const void*)potrf_trtri_leaf128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(potrf_trtri_leaf128_kernel, dim3(1), dim3(256), lds_bytes, h->stream, A, lda, X, ldx, b, want_inv, zero_lower,
                        invert_only, unit, h->d_info, info_base);
-  else
-    hipLaunchKernelGGL(potrf_trtri_leaf_kernel<8>, dim3(1), dim3(256), 0, h->stream, A, lda, X, ldx, b, want_inv, zero_lower,
-                       invert_only, unit, h->d_info, info_base);
+  }
   CAPI_HIP_CHECK(h, hipGetLastError());
   return CAPI_OK;
 }

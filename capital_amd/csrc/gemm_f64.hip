@@ -169,7 +169,11 @@ __device__ __forceinline__ void tile_of(const GemmArgs& p, int t, int& ti, int& 
     const int first_m = group * GROUP_M;
     const int gsz = min(nm - first_m, GROUP_M);
     const int loc = t - group * in_group;
-    const int a = first_m + loc % gsz, b = loc / gsz;
+    const int a = first_m + loc % gsz;
+    int b = loc / gsz;
+    // a TRMM tile's k-range grows linearly along b: pair short with long so that every contiguous chunk of ids (an
+    // XCD's share, or what a CU sees over time) carries the average amount of work
+    if (p.tri_side >= 0) b = (b & 1) ? nn - 1 - (b >> 1) : (b >> 1);
     ti = by_cols ? b : a;
     tj = by_cols ? a : b;
   } else {
@@ -353,9 +357,36 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
     CAPI_HIP_CHECK(h, hipGetLastError());
     return CAPI_OK;
   }
-  // tile size: 128 when that alone fills the chip twice over (2 workgroups per CU), else 64
-  const int64_t slots = 2 * (int64_t)h->num_cu;
-  p.ts = count_tiles(p, 128) >= slots ? 128 : 64;
+  // Choose tile size and split-K from a small cost model (all in microseconds, MFMA-bound regime):
+  //   a CU runs 2 workgroups of 128-tiles or 4 of 64-tiles; with the CU fully subscribed one k-panel (16) of a tile costs
+  //   64 MFMA * 64 cycles * 2 (128) or 16 * 64 * 4 (64) cycles, i.e. the same area rate -- so the choice is about ROUNDS:
+  //   time = ceil(tiles * s / slots) * tile_time(K / s) + reduce(s).  Splitting K trades a partial last round for a slab pass.
+  const bool tri = p.tri_side >= 0;
+  const double us_per_k16_128 = 8192.0 / 2200.0, us_per_k16_64 = 4096.0 / 2200.0;   // at ~2.2 GHz
+  double best = 1e300;
+  int best_ts = 128, best_s = 1;
+  for (int ts : {128, 64}) {
+    const double nt = (double)count_tiles(p, ts);
+    const double slots = (ts == 128 ? 2.0 : 4.0) * h->num_cu;
+    const double keff = tri ? 0.5 * p.K + 0.5 * ts : (double)p.K;       // average k-range of a TRMM tile
+    for (int sk : {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256}) {
+      if (sk > 1 && (!ws_for_slab || p.K / sk < 256)) break;
+      const double rounds = ceil(nt * sk / slots);
+      // below one full round the CU is under-subscribed and a tile runs proportionally faster
+      const double fill = nt * sk / slots;
+      const double share = fill >= 1.0 ? 1.0 : (fill > 1.0 / (ts == 128 ? 2.0 : 4.0) ? fill : 1.0 / (ts == 128 ? 2.0 : 4.0));
+      // the 64-tile kernel pays twice the LDS/L2 traffic and barriers per flop: measured ~12 % slower at equal rounds
+      double t = rounds * share * (keff / sk / 16.0) * (ts == 128 ? us_per_k16_128 : 1.12 * us_per_k16_64) + 6.0;
+      // operand panels stream from L2/MALL: ~4 TB/s effective when every tile re-reads its two panels
+      const double t_mem = nt * 2.0 * ts * keff * 8.0 / 4.0e6;
+      if (t_mem > t) t = t_mem;
+      if (sk > 1) t = 1.03 * t + 6.0 + (double)(sk + 2) * (double)p.M * (double)p.N * (p.out_uplo >= 0 ? 0.5 : 1.0) * 8.0 / 2.5e6;
+      if (t < best) { best = t; best_ts = ts; best_s = sk; }
+    }
+  }
+  static const bool dbg = getenv("CAPI_DEBUG_GEMM") != nullptr;
+  if (dbg) fprintf(stderr, "[capi gemm] M=%d N=%d K=%d uplo=%d tri=%d -> ts=%d splitk=%d est=%.1f us\n", p.M, p.N, p.K, p.out_uplo, p.tri_side, best_ts, best_s, best);
+  p.ts = best_ts;
   p.tiles_m = (int)cdiv(p.M, p.ts);
   p.tiles_n = (int)cdiv(p.N, p.ts);
   p.ntiles = (int)count_tiles(p, p.ts);
@@ -365,25 +396,18 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
   p.k_per_split = p.K;
   p.slab = nullptr;
   p.slab_ld = p.slab_stride = 0;
-  // split-K when even the small tiling leaves CUs idle: tall-skinny Gram matrices (K = m_loc >> n) and the
-  // small levels of the recursion.  Slices are at least 128 deep and the grid is filled about twice.
-  if (ws_for_slab && p.ntiles < slots && p.K >= 512) {
-    int64_t sk = cdiv(2 * slots, p.ntiles);
-    const int64_t max_sk = p.K / 128;
-    if (sk > max_sk) sk = max_sk;
+  if (best_s > 1) {
+    const int64_t kps = cdiv(cdiv(p.K, best_s), BK) * BK;
+    const int64_t sk = cdiv(p.K, kps);
     if (sk > 1) {
-      const int64_t kps = cdiv(cdiv(p.K, sk), BK) * BK;
-      sk = cdiv(p.K, kps);
-      if (sk > 1) {
-        p.splitk = (int)sk;
-        p.k_per_split = (int)kps;
-        p.slab_ld = p.M;
-        p.slab_stride = (int64_t)p.M * p.N;
-        void* ws;
-        int rc = capi_ws_get(h, sizeof(double) * (size_t)p.slab_stride * (size_t)sk, &ws);
-        if (rc != CAPI_OK) return rc;
-        p.slab = (double*)ws;
-      }
+      p.splitk = (int)sk;
+      p.k_per_split = (int)kps;
+      p.slab_ld = p.M;
+      p.slab_stride = (int64_t)p.M * p.N;
+      void* ws;
+      int rc = capi_ws_get(h, sizeof(double) * (size_t)p.slab_stride * (size_t)sk, &ws);
+      if (rc != CAPI_OK) return rc;
+      p.slab = (double*)ws;
     }
   }
   gemm_kernel_t k = p.ts == 128 ? pick_kernel<128>(ak, bkc) : pick_kernel<64>(ak, bkc);

@@ -53,6 +53,7 @@ public:
     DimensionType localDimension = 0, globalDimension = 0, trueLocalDimension = 0, trueGlobalDimension = 0, bcDimension = 0;
     // bookkeeping exposed for tests / benches
     int64_t num_base_cases = 0, num_levels = 0;
+    bool zeroed = false;
   };
 
   template <typename MatrixType, typename ArgType, typename CommType>
@@ -74,8 +75,13 @@ public:
     double* Ri = packed ? args.Rinvfull.data() : (double*)args.Rinv.data();
     const U ld = localDimension;
     // cholinv.hpp:13: the upper triangle of the input becomes the working R; the rest of R and all of R^-1 are zero
-    capital::dev_zero(R, ld * ld);
-    capital::dev_zero(Ri, ld * ld);
+    // Freshly registered blocks are zero (matrix::allocate) and nothing below ever stores a non-zero where the result
+    // must be zero (strictly-lower parts; the skipped R^-1_12 at the top level), so later calls do not re-zero 2 n_loc^2.
+    if (!args.zeroed) {
+      capital::dev_zero(R, ld * ld);
+      capital::dev_zero(Ri, ld * ld);
+      args.zeroed = true;
+    }
     CAPITAL_CHECK(capi_dlacpy(capital::handle(), 1, ld, ld, A.data(), ld, R, ld));
 
     // base-case size rule, cholinv.hpp:15-18

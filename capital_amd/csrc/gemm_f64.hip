@@ -101,6 +101,14 @@ __device__ __forceinline__ void panel_load(const double* __restrict__ X, int64_t
   }
 }
 
+// interior fast path: the whole panel is in range and 16-byte aligned -- four straight-line loads, no predicates.
+// `base` already points at this thread's first piece of the panel; `stride` (elements) separates its pieces.
+template <int TS>
+__device__ __forceinline__ void panel_load_fast(const double* __restrict__ base, int64_t stride, d2_t (&v)[TS / 32]) {
+#pragma unroll
+  for (int q = 0; q < TS / 32; ++q) v[q] = *(const d2_t*)(base + q * stride);
+}
+
 // zero what lies outside the triangle of op(T) (and force a unit diagonal) on a staged panel.
 // keep_ge: keep k >= r, else keep k <= r  (r = the panel's row index in op(T) coordinates)
 template <int TS, bool KC>
@@ -226,6 +234,15 @@ __global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel
 #pragma unroll
     for (int b = 0; b < SUB; ++b) acc[a][b] = (d4_t){0.0, 0.0, 0.0, 0.0};
 
+  // per-thread source of the fast path (see panel_load for the thread -> element map)
+  const bool interior = (i0 + BM <= p.M) && (j0 + BN <= p.N) && p.a_vec && p.b_vec;
+  const double* fa = AK ? p.A + (int64_t)(i0 + (tid >> 3)) * p.lda + klo + 2 * (tid & 7)
+                        : p.A + (int64_t)(klo + tid / (TS / 2)) * p.lda + i0 + 2 * (tid & (TS / 2 - 1));
+  const double* fb = BKC ? p.B + (int64_t)(j0 + (tid >> 3)) * p.ldb + klo + 2 * (tid & 7)
+                         : p.B + (int64_t)(klo + tid / (TS / 2)) * p.ldb + j0 + 2 * (tid & (TS / 2 - 1));
+  const int64_t qsa = AK ? 32 * p.lda : (512 / TS) * p.lda, qsb = BKC ? 32 * p.ldb : (512 / TS) * p.ldb;
+  const int64_t ksa = AK ? BK : BK * p.lda, ksb = BKC ? BK : BK * p.ldb;
+
   d2_t ra[NQ], rb[NQ];
   if (ntk > 0) {
     panel_load<TS, AK>(p.A, p.lda, i0, p.M, klo, khi, tid, p.a_vec, ra);
@@ -243,8 +260,15 @@ __global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel
     const int kn = klo + (t + 1) * BK;
     const bool more = (t + 1 < ntk);
     if (more) {
-      panel_load<TS, AK>(p.A, p.lda, i0, p.M, kn, khi, tid, p.a_vec, ra);
-      panel_load<TS, BKC>(p.B, p.ldb, j0, p.N, kn, khi, tid, p.b_vec, rb);
+      fa += ksa;
+      fb += ksb;
+      if (interior && kn + BK <= khi) {
+        panel_load_fast<TS>(fa, qsa, ra);
+        panel_load_fast<TS>(fb, qsb, rb);
+      } else {
+        panel_load<TS, AK>(p.A, p.lda, i0, p.M, kn, khi, tid, p.a_vec, ra);
+        panel_load<TS, BKC>(p.B, p.ldb, j0, p.N, kn, khi, tid, p.b_vec, rb);
+      }
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -369,14 +393,16 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
     const double nt = (double)count_tiles(p, ts);
     const double slots = (ts == 128 ? 2.0 : 4.0) * h->num_cu;
     const double keff = tri ? 0.5 * p.K + 0.5 * ts : (double)p.K;       // average k-range of a TRMM tile
-    for (int sk : {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256}) {
+    const int spc = ts == 128 ? 2 : 4;                                   // resident workgroups per CU
+    for (int sk = 1; sk <= 512; ++sk) {
       if (sk > 1 && (!ws_for_slab || p.K / sk < 256)) break;
-      const double rounds = ceil(nt * sk / slots);
-      // below one full round the CU is under-subscribed and a tile runs proportionally faster
-      const double fill = nt * sk / slots;
-      const double share = fill >= 1.0 ? 1.0 : (fill > 1.0 / (ts == 128 ? 2.0 : 4.0) ? fill : 1.0 / (ts == 128 ? 2.0 : 4.0));
-      // the 64-tile kernel pays twice the LDS/L2 traffic and barriers per flop: measured ~12 % slower at equal rounds
-      double t = rounds * share * (keff / sk / 16.0) * (ts == 128 ? us_per_k16_128 : 1.12 * us_per_k16_64) + 6.0;
+      // full rounds at full subscription, then a last round in which the busiest CU holds ceil(rem / CUs) workgroups
+      // (a workgroup alone on a CU runs spc times faster than at full subscription)
+      const int64_t units = (int64_t)nt * sk, full = units / (int64_t)slots, rem = units - full * (int64_t)slots;
+      const double rounds = (double)full + (double)cdiv(rem, h->num_cu) / spc;
+      const double share = 1.0;
+      // the 64-tile kernel pays twice the LDS/L2 traffic and barriers per flop: measured a few % slower at equal rounds
+      double t = rounds * share * (keff / sk / 16.0) * (ts == 128 ? us_per_k16_128 : 1.06 * us_per_k16_64) + 6.0;
       // operand panels stream from L2/MALL: ~4 TB/s effective when every tile re-reads its two panels
       const double t_mem = nt * 2.0 * ts * keff * 8.0 / 4.0e6;
       if (t_mem > t) t = t_mem;
@@ -384,6 +410,8 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
       if (t < best) { best = t; best_ts = ts; best_s = sk; }
     }
   }
+  static const char* force_ts = getenv("CAPI_FORCE_TS");
+  if (force_ts) { best_ts = atoi(force_ts); best_s = 1; }
   static const bool dbg = getenv("CAPI_DEBUG_GEMM") != nullptr;
   if (dbg) fprintf(stderr, "[capi gemm] M=%d N=%d K=%d uplo=%d tri=%d -> ts=%d splitk=%d est=%.1f us\n", p.M, p.N, p.K, p.out_uplo, p.tri_side, best_ts, best_s, best);
   p.ts = best_ts;
@@ -453,9 +481,12 @@ __global__ __launch_bounds__(256) void mfma_f64_peak_kernel(double* out, int ite
 #pragma unroll
   for (int q = 0; q < 8; ++q) acc[q] = (d4_t){0.0, 0.0, 0.0, 0.0};
   for (int it = 0; it < iters; ++it) {
+    // inline asm pins the accumulators in VGPRs: with the builtin hipcc shuttles all 64 of them through AGPRs
+    // every iteration (128 v_accvgpr moves per 8 MFMAs) and the loop measures that traffic, not the matrix pipe
 #pragma unroll
-    for (int q = 0; q < 8; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[q], 0, 0, 0);
+    for (int q = 0; q < 8; ++q) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[q]) : "v"(a), "v"(b));
   }
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // let the last MFMAs retire before their results are read
   double s = 0.0;
 #pragma unroll
   for (int q = 0; q < 8; ++q) s += acc[q][0] + acc[q][1] + acc[q][2] + acc[q][3];
@@ -584,7 +615,8 @@ int capi_prof_collect(capi_handle_t h, int variant, int64_t* launches, double* t
 
 int capi_mfma_f64_peak(capi_handle_t h, int iters, double* tflops) {
   CAPI_REQUIRE(h, h && tflops && iters > 0, "args");
-  const int blocks = h->num_cu * 2;  // 2 x 4 waves per CU = 2 waves per SIMD
+  const char* bpc = getenv("CAPI_PEAK_BLOCKS_PER_CU");
+  const int blocks = h->num_cu * (bpc ? atoi(bpc) : 1);  // 4 waves per block: one block per CU = one wave per SIMD
   double* out;
   CAPI_HIP_CHECK(h, hipMalloc((void**)&out, sizeof(double) * blocks * 256));
   hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, h->stream, out, 16);  // warm-up

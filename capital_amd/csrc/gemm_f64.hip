@@ -55,6 +55,8 @@ struct GemmArgs {
   int64_t slab_ld, slab_stride;
   int tiles_m, tiles_n, ntiles;
   int ts;             // tile size chosen by the launcher
+  int no_skip;        // diagnostics: never skip zero sub-tiles
+  int share_ab;       // A and B are the same matrix in the same orientation (syrk): diagonal tiles stage ONE panel
 };
 
 // ---- global -> registers: this thread's 4 x 16 bytes of a 128 x 16 operand panel -----------------
@@ -166,6 +168,28 @@ __device__ __forceinline__ d2_t frag_read(const double* __restrict__ L, int row,
   }
 }
 
+// One k-step (4 deep) of the wave's SUB x SUB MFMA tiles.  `keep` has one bit per (a,b) sub-tile: sub-tiles that are
+// provably all-zero products (below the diagonal of a triangular output tile, or outside the band of a triangular
+// operand in the diagonal zone of a TRMM tile) are skipped at MFMA granularity (16 x 16) instead of tile granularity.
+template <int SUB, int COMP>
+__device__ __forceinline__ void mfma_step(d4_t (&acc)[SUB][SUB], const d2_t (&af)[SUB], const d2_t (&bf)[SUB], unsigned keep) {
+  constexpr unsigned FULL = (1u << (SUB * SUB)) - 1u;
+  if (keep == FULL) {
+#pragma unroll
+    for (int a = 0; a < SUB; ++a)
+#pragma unroll
+      for (int b = 0; b < SUB; ++b)
+        acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(COMP ? bf[b].y : bf[b].x, COMP ? af[a].y : af[a].x, acc[a][b], 0, 0, 0);
+  } else {
+#pragma unroll
+    for (int a = 0; a < SUB; ++a)
+#pragma unroll
+      for (int b = 0; b < SUB; ++b)
+        if (keep & (1u << (a * SUB + b)))
+          acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(COMP ? bf[b].y : bf[b].x, COMP ? af[a].y : af[a].x, acc[a][b], 0, 0, 0);
+  }
+}
+
 __device__ __forceinline__ void tile_of(const GemmArgs& p, int t, int& ti, int& tj) {
   if (p.out_uplo < 0) {
     // bands of GROUP_M tile-rows (all tile-columns) are dealt to XCDs in order.  A left-side TRMM's work per tile
@@ -226,6 +250,7 @@ __global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel
   }
   const int ntk = khi > klo ? (khi - klo + BK - 1) / BK : 0;
   const bool maskA = p.tri_side == CAPI_LEFT, maskB = p.tri_side == CAPI_RIGHT;
+  const bool shareB = AK == BKC && p.share_ab && ti == tj;   // B panel == A panel: load and stage it once
   const bool keep_ge = (p.tri_side == CAPI_LEFT) == (p.tri_eff_upper != 0);
 
   d4_t acc[SUB][SUB];
@@ -243,20 +268,33 @@ __global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel
   const int64_t qsa = AK ? 32 * p.lda : (512 / TS) * p.lda, qsb = BKC ? 32 * p.ldb : (512 / TS) * p.ldb;
   const int64_t ksa = AK ? BK : BK * p.lda, ksb = BKC ? BK : BK * p.ldb;
 
+  // triangular output: on a diagonal tile the sub-tiles lying entirely in the unwanted triangle are never computed
+  unsigned out_keep = (1u << (SUB * SUB)) - 1u;
+  if (p.out_uplo >= 0 && ti == tj && !p.no_skip) {
+#pragma unroll
+    for (int a = 0; a < SUB; ++a)
+#pragma unroll
+      for (int b = 0; b < SUB; ++b) {
+        const int rlo = wm * (TS / 2) + 16 * a, clo = wn * (TS / 2) + 16 * b;
+        const bool on = p.out_uplo == CAPI_UPPER ? (rlo <= clo + 15) : (rlo + 15 >= clo);
+        if (!on) out_keep &= ~(1u << (a * SUB + b));
+      }
+  }
+
   d2_t ra[NQ], rb[NQ];
   if (ntk > 0) {
     panel_load<TS, AK>(p.A, p.lda, i0, p.M, klo, khi, tid, p.a_vec, ra);
-    panel_load<TS, BKC>(p.B, p.ldb, j0, p.N, klo, khi, tid, p.b_vec, rb);
+    if (!shareB) panel_load<TS, BKC>(p.B, p.ldb, j0, p.N, klo, khi, tid, p.b_vec, rb);
     if (maskA && klo < i0 + BM && klo + BK > i0) panel_mask<TS, AK>(i0, klo, tid, keep_ge, p.tri_unit, ra);
     if (maskB && klo < j0 + BN && klo + BK > j0) panel_mask<TS, BKC>(j0, klo, tid, keep_ge, p.tri_unit, rb);
     panel_store<TS, AK>(lds, tid, ra);
-    panel_store<TS, BKC>(lds + TILE_LDS, tid, rb);
+    if (!shareB) panel_store<TS, BKC>(lds + TILE_LDS, tid, rb);
   }
   __syncthreads();
 
   for (int t = 0; t < ntk; ++t) {
     const double* La = lds + (t & 1) * STAGE_LDS;
-    const double* Lb = La + TILE_LDS;
+    const double* Lb = shareB ? La : La + TILE_LDS;
     const int kn = klo + (t + 1) * BK;
     const bool more = (t + 1 < ntk);
     if (more) {
@@ -264,11 +302,32 @@ __global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel
       fb += ksb;
       if (interior && kn + BK <= khi) {
         panel_load_fast<TS>(fa, qsa, ra);
-        panel_load_fast<TS>(fb, qsb, rb);
+        if (!shareB) panel_load_fast<TS>(fb, qsb, rb);
       } else {
         panel_load<TS, AK>(p.A, p.lda, i0, p.M, kn, khi, tid, p.a_vec, ra);
-        panel_load<TS, BKC>(p.B, p.ldb, j0, p.N, kn, khi, tid, p.b_vec, rb);
+        if (!shareB) panel_load<TS, BKC>(p.B, p.ldb, j0, p.N, kn, khi, tid, p.b_vec, rb);
       }
+    }
+    // sub-tile activity of this wave for this panel (wave-uniform)
+    unsigned keep = out_keep;
+    const int kk = klo + t * BK;
+    // only panels that cross the diagonal band of this tile can have dead sub-tiles
+    const bool band = p.tri_side == CAPI_LEFT ? (kk < i0 + BM && kk + BK > i0) : (kk < j0 + BN && kk + BK > j0);
+    if (p.tri_side >= 0 && band && !p.no_skip) {
+#pragma unroll
+      for (int a = 0; a < SUB; ++a)
+#pragma unroll
+        for (int b = 0; b < SUB; ++b) {
+          bool on;
+          if (p.tri_side == CAPI_LEFT) {
+            const int rlo = i0 + wm * (TS / 2) + 16 * a;
+            on = p.tri_eff_upper ? (kk + BK - 1 >= rlo) : (kk <= rlo + 15);
+          } else {
+            const int clo = j0 + wn * (TS / 2) + 16 * b;
+            on = p.tri_eff_upper ? (kk <= clo + 15) : (kk + BK - 1 >= clo);
+          }
+          if (!on) keep &= ~(1u << (a * SUB + b));
+        }
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -277,23 +336,15 @@ __global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel
       for (int a = 0; a < SUB; ++a) af[a] = frag_read<TS, AK>(La, wm * (TS / 2) + a * 16 + r16, u, g);
 #pragma unroll
       for (int b = 0; b < SUB; ++b) bf[b] = frag_read<TS, BKC>(Lb, wn * (TS / 2) + b * 16 + r16, u, g);
-#pragma unroll
-      for (int a = 0; a < SUB; ++a)
-#pragma unroll
-        for (int b = 0; b < SUB; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].x, af[a].x, acc[a][b], 0, 0, 0);
-#pragma unroll
-      for (int a = 0; a < SUB; ++a)
-#pragma unroll
-        for (int b = 0; b < SUB; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[b].y, af[a].y, acc[a][b], 0, 0, 0);
+      mfma_step<SUB, 0>(acc, af, bf, keep);
+      mfma_step<SUB, 1>(acc, af, bf, keep);
     }
     if (more) {
       if (maskA && kn < i0 + BM && kn + BK > i0) panel_mask<TS, AK>(i0, kn, tid, keep_ge, p.tri_unit, ra);
       if (maskB && kn < j0 + BN && kn + BK > j0) panel_mask<TS, BKC>(j0, kn, tid, keep_ge, p.tri_unit, rb);
       double* Na = lds + ((t + 1) & 1) * STAGE_LDS;
       panel_store<TS, AK>(Na, tid, ra);
-      panel_store<TS, BKC>(Na + TILE_LDS, tid, rb);
+      if (!shareB) panel_store<TS, BKC>(Na + TILE_LDS, tid, rb);
     }
     __syncthreads();
   }
@@ -389,7 +440,9 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
   const double us_per_k16_128 = 8192.0 / 2200.0, us_per_k16_64 = 4096.0 / 2200.0;   // at ~2.2 GHz
   double best = 1e300;
   int best_ts = 128, best_s = 1;
+  static const char* force_ts = getenv("CAPI_FORCE_TS");
   for (int ts : {128, 64}) {
+    if (force_ts && atoi(force_ts) != ts) continue;
     const double nt = (double)count_tiles(p, ts);
     const double slots = (ts == 128 ? 2.0 : 4.0) * h->num_cu;
     const double keff = tri ? 0.5 * p.K + 0.5 * ts : (double)p.K;       // average k-range of a TRMM tile
@@ -404,14 +457,14 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
       // the 64-tile kernel pays twice the LDS/L2 traffic and barriers per flop: measured a few % slower at equal rounds
       double t = rounds * share * (keff / sk / 16.0) * (ts == 128 ? us_per_k16_128 : 1.06 * us_per_k16_64) + 6.0;
       // operand panels stream from L2/MALL: ~4 TB/s effective when every tile re-reads its two panels
-      const double t_mem = nt * 2.0 * ts * keff * 8.0 / 4.0e6;
+      // (a syrk's diagonal tiles stage one panel; a TRMM's triangular operand is small and stays cache resident)
+      const double panels = (p.out_uplo >= 0 && p.A == p.B) ? 2.0 * nt - (double)cdiv(p.N, ts) : (tri ? 1.0 * nt : 2.0 * nt);
+      const double t_mem = panels * ts * keff * 8.0 / 4.0e6;
       if (t_mem > t) t = t_mem;
       if (sk > 1) t = 1.03 * t + 6.0 + (double)(sk + 2) * (double)p.M * (double)p.N * (p.out_uplo >= 0 ? 0.5 : 1.0) * 8.0 / 2.5e6;
       if (t < best) { best = t; best_ts = ts; best_s = sk; }
     }
   }
-  static const char* force_ts = getenv("CAPI_FORCE_TS");
-  if (force_ts) { best_ts = atoi(force_ts); best_s = 1; }
   static const bool dbg = getenv("CAPI_DEBUG_GEMM") != nullptr;
   if (dbg) fprintf(stderr, "[capi gemm] M=%d N=%d K=%d uplo=%d tri=%d -> ts=%d splitk=%d est=%.1f us\n", p.M, p.N, p.K, p.out_uplo, p.tri_side, best_ts, best_s, best);
   p.ts = best_ts;
@@ -420,6 +473,8 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
   p.ntiles = (int)count_tiles(p, p.ts);
   p.a_vec = (((uintptr_t)p.A & 15) == 0) && ((p.lda & 1) == 0);
   p.b_vec = (((uintptr_t)p.B & 15) == 0) && ((p.ldb & 1) == 0);
+  p.no_skip = getenv("CAPI_NO_SKIP") ? 1 : 0;
+  p.share_ab = (p.out_uplo >= 0 && p.A == p.B && p.lda == p.ldb && ak == bkc && !getenv("CAPI_NO_SHARE")) ? 1 : 0;
   p.splitk = 1;
   p.k_per_split = p.K;
   p.slab = nullptr;

@@ -94,7 +94,10 @@ def main():
     n, c = CHOLESKY_GRID[args.gpus]
     if args.n:
         n = args.n
-    prob = driver.Cholinv(n, c=c, complete_inv=0, split=1, bc_mult=args.bc, layout=0, num_chunks=0, serialize=True, bc_policy=0 if distributed else 2)
+    # num_chunks > 0 turns on the chunked SUMMA pipeline (collectives on a second HIP stream beside the tile kernel).
+    # Off by default until the plain path has been seen to run on a multi-GPU node.
+    chunks = int(os.environ.get("CAPITAL_BENCH_CHUNKS", "0")) if distributed else 0
+    prob = driver.Cholinv(n, c=c, complete_inv=0, split=1, bc_mult=args.bc, layout=0, num_chunks=chunks, serialize=True, bc_policy=0 if distributed else 2)
     prob.generate()
     for _ in range(args.warmup):
         prob.factor()
@@ -128,7 +131,7 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"n={n} recursive Cholesky with inverse (cholinv, complete_inv=0, split=1, bc_mult={args.bc}) on a {prob.d}x{prob.d}x{prob.c} GPU grid",
-                   "n": n, "grid": [prob.d, prob.d, prob.c], "base_case_order": stats["bc_dimension"], "residual": residual},
+                   "n": n, "grid": [prob.d, prob.d, prob.c], "base_case_order": stats["bc_dimension"], "residual": residual, "summa_chunks": chunks},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": None,
                      "kernel": "dgemm_tile_kernel<true,true> (trailing update + R12 solve)",

@@ -42,6 +42,9 @@ int capi_destroy(capi_handle_t h) {
   if (!h) return CAPI_EINVAL;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
+  if (h->streams[1]) { (void)hipStreamSynchronize(h->streams[1]); (void)hipStreamDestroy(h->streams[1]); }
+  if (h->streams[0]) h->stream = h->streams[0];
+  if (h->events) { for (int i = 0; i < 1024; ++i) if (h->events[i]) (void)hipEventDestroy(h->events[i]); free(h->events); }
   if (h->ws) (void)hipFree(h->ws);
   if (h->ws2) (void)hipFree(h->ws2);
   if (h->d_info) (void)hipFree(h->d_info);
@@ -96,6 +99,8 @@ int capi_memcpy_d2d_async(capi_handle_t h, void* d, const void* s, size_t bytes)
 }
 int capi_sync(capi_handle_t h) {
   CAPI_REQUIRE(h, h, "null handle");
+  if (h->streams[1]) CAPI_HIP_CHECK(h, hipStreamSynchronize(h->streams[1]));
+  if (h->streams[0]) CAPI_HIP_CHECK(h, hipStreamSynchronize(h->streams[0]));
   CAPI_HIP_CHECK(h, hipStreamSynchronize(h->stream));
   return CAPI_OK;
 }
@@ -115,6 +120,41 @@ int capi_get_info(capi_handle_t h, int* info) {
 int capi_reset_info(capi_handle_t h) {
   CAPI_REQUIRE(h, h, "null handle");
   CAPI_HIP_CHECK(h, hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
+  return CAPI_OK;
+}
+
+int capi_stream_select(capi_handle_t h, int which) {
+  CAPI_REQUIRE(h, h && (which == 0 || which == 1), "stream index");
+  if (!h->streams[0]) h->streams[0] = h->stream;
+  if (which == 1 && !h->streams[1]) {
+    CAPI_HIP_CHECK(h, hipSetDevice(h->device));
+    CAPI_HIP_CHECK(h, hipStreamCreateWithFlags(&h->streams[1], hipStreamNonBlocking));
+  }
+  h->stream = h->streams[which];
+  return CAPI_OK;
+}
+static int event_slot(capi_handle_t h, int slot, hipEvent_t** ev) {
+  CAPI_REQUIRE(h, h && slot >= 0 && slot < 1024, "event slot");
+  if (!h->events) {
+    h->events = (hipEvent_t*)calloc(1024, sizeof(hipEvent_t));
+    if (!h->events) return CAPI_ENOMEM;
+  }
+  if (!h->events[slot]) CAPI_HIP_CHECK(h, hipEventCreateWithFlags(&h->events[slot], hipEventDisableTiming));
+  *ev = &h->events[slot];
+  return CAPI_OK;
+}
+int capi_event_record(capi_handle_t h, int slot) {
+  hipEvent_t* ev;
+  int rc = event_slot(h, slot, &ev);
+  if (rc != CAPI_OK) return rc;
+  CAPI_HIP_CHECK(h, hipEventRecord(*ev, h->stream));
+  return CAPI_OK;
+}
+int capi_event_wait(capi_handle_t h, int slot) {
+  hipEvent_t* ev;
+  int rc = event_slot(h, slot, &ev);
+  if (rc != CAPI_OK) return rc;
+  CAPI_HIP_CHECK(h, hipStreamWaitEvent(h->stream, *ev, 0));
   return CAPI_OK;
 }
 

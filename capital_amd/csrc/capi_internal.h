@@ -10,6 +10,9 @@ struct capi_handle_s {
   int device = 0;
   hipStream_t stream = nullptr;
   bool owns_stream = false;
+  // stream[0] = compute (== the handle's primary stream), stream[1] = communication, created on first select
+  hipStream_t streams[2] = {nullptr, nullptr};
+  hipEvent_t* events = nullptr;   // 1024 lazily created slots
   // private workspace (in-place trmm staging, split-K slabs, potrf panels); grows on demand
   void* ws = nullptr;
   size_t ws_bytes = 0;

@@ -126,8 +126,38 @@ public:
     ws.top = mark;
   }
 
+  // Cross-stream pipeline helper: with num_chunks > 0 the collectives of a multiply run on the handle's communication
+  // stream beside the tile kernel on the compute stream (the reference's MPI_Ibcast/MPI_Iallreduce chunking,
+  // summa.hpp:195-215,238-249).  Host calls are issued in an order that is also valid when executed sequentially.
+  struct pipe {
+    capi_handle_t h;
+    bool on;
+    int base;
+    explicit pipe(bool enable) : h(capital::handle()), on(enable) {
+      static int next = 0;
+      base = next;
+      next = (next + 256) % 1024;
+    }
+    void comm() { if (on) CAPITAL_CHECK(capi_stream_select(h, 1)); }
+    void main() { if (on) CAPITAL_CHECK(capi_stream_select(h, 0)); }
+    void rec(int s) { if (on) CAPITAL_CHECK(capi_event_record(h, base + s)); }
+    void wait(int s) { if (on) CAPITAL_CHECK(capi_event_wait(h, base + s)); }
+  };
+  static int chunk_count(size_t num_chunks, int64_t cols) {
+    static const int64_t min_cols = getenv("CAPITAL_MIN_CHUNK_COLS") ? std::max(2, atoi(getenv("CAPITAL_MIN_CHUNK_COLS"))) : 128;   // tests shrink it
+    int n = (int)std::min<int64_t>((int64_t)std::min<size_t>(num_chunks, 64), std::max<int64_t>(cols / min_cols, 1));
+    return n < 1 ? 1 : n;
+  }
+  // column range of chunk j (multiples of 2 columns keep 16-byte alignment)
+  static void chunk_range(int64_t cols, int nch, int j, int64_t& c0, int64_t& c1) {
+    const int64_t per = ((cols + nch - 1) / nch + 1) & ~(int64_t)1;
+    c0 = std::min<int64_t>(cols, per * j);
+    c1 = std::min<int64_t>(cols, c0 + per);
+  }
+
   // Cout <- alpha*op(T)*B (Left) or alpha*B*op(T) (Right); T is this rank's block of a triangular matrix.
   // Left: T travels along `row`, B along `column`; Right: B along `row`, T along `column` (summa.hpp:59-71).
+  // Cout must be contiguous (ld == rows) when the grid has more than one rank.
   template <typename CommType>
   static void trmm(CommType&& t, int side, int uplo, int trans, int diag, double alpha, view T, view B, view Cout, arena& ws) {
     capi_handle_t h = capital::handle();
@@ -137,36 +167,54 @@ public:
       return;
     }
     const int64_t mark = ws.top;
+    const size_t steps = t.d > 1 ? t.d / t.c : 1;
+    // the output-column pipeline is built for the one-step cases (c == d as in the reference, or d == 1) of a left multiply
+    const bool piped = t.num_chunks > 0 && side == CAPI_LEFT && steps == 1 && Cout.contiguous();
+    const int nch = piped ? chunk_count(t.num_chunks, N) : 1;
+    pipe P(piped && nch > 1);
+    enum { E0 = 0, ET = 1, EB = 2, EC = 70, ER = 140 };
     if (t.d == 1) {
       // K-slice [k0,k1) of a triangular operand: a triangle on the diagonal plus a rectangle beside it
       const int64_t K = T.rows;
       int64_t k0, k1;
       kslice(K, t.c, t.z, k0, k1);
       const bool eff_upper = (uplo == CAPI_UPPER) != (trans == CAPI_TRANS);
-      CAPITAL_CHECK(capi_dgeadd(h, 0, M, N, 0.0, Cout.p, Cout.ld, 0.0, Cout.p, Cout.ld));   // Cout = 0
-      if (k1 > k0) {
-        const double* Tkk = T.p + k0 + k0 * T.ld;
+      for (int j = 0; j < nch; ++j) {
+        int64_t c0 = 0, c1 = N;
+        if (nch > 1) chunk_range(N, nch, j, c0, c1);
+        const int64_t nc = c1 - c0;
+        if (nc <= 0) continue;
         if (side == CAPI_LEFT) {
-          // rows of op(T) that see K-columns [k0,k1): the diagonal block rows [k0,k1) and, above (eff upper) or below them, a rectangle
-          CAPITAL_CHECK(capi_dtrmm_oop(h, side, uplo, trans, diag, k1 - k0, N, alpha, Tkk, T.ld, B.p + k0, B.ld, Cout.p + k0, Cout.ld));
-          const int64_t r0 = eff_upper ? 0 : k1, r1 = eff_upper ? k0 : K;
-          if (r1 > r0) {
-            // E[r0:r1, k0:k1] = trans ? T[k0:k1, r0:r1]^T : T[r0:r1, k0:k1]
-            const double* Tr = trans ? T.p + k0 + r0 * T.ld : T.p + r0 + k0 * T.ld;
-            CAPITAL_CHECK(capi_dgemm(h, trans, CAPI_NOTRANS, r1 - r0, N, k1 - k0, alpha, Tr, T.ld, B.p + k0, B.ld, 0.0, Cout.p + r0, Cout.ld));
+          const double* Bj = B.p + c0 * B.ld;
+          double* Cj = Cout.p + c0 * Cout.ld;
+          CAPITAL_CHECK(capi_dgeadd(h, 0, M, nc, 0.0, Cj, Cout.ld, 0.0, Cj, Cout.ld));   // Cj = 0
+          if (k1 > k0) {
+            const double* Tkk = T.p + k0 + k0 * T.ld;
+            // rows of op(T) that see K-columns [k0,k1): the diagonal block rows and, above (eff upper) or below them, a rectangle
+            CAPITAL_CHECK(capi_dtrmm_oop(h, side, uplo, trans, diag, k1 - k0, nc, alpha, Tkk, T.ld, Bj + k0, B.ld, Cj + k0, Cout.ld));
+            const int64_t r0 = eff_upper ? 0 : k1, r1 = eff_upper ? k0 : K;
+            if (r1 > r0) {
+              // E[r0:r1, k0:k1] = trans ? T[k0:k1, r0:r1]^T : T[r0:r1, k0:k1]
+              const double* Tr = trans ? T.p + k0 + r0 * T.ld : T.p + r0 + k0 * T.ld;
+              CAPITAL_CHECK(capi_dgemm(h, trans, CAPI_NOTRANS, r1 - r0, nc, k1 - k0, alpha, Tr, T.ld, Bj + k0, B.ld, 0.0, Cj + r0, Cout.ld));
+            }
           }
+          P.rec(EC + j);
         } else {
-          CAPITAL_CHECK(capi_dtrmm_oop(h, side, uplo, trans, diag, M, k1 - k0, alpha, Tkk, T.ld, B.p + k0 * B.ld, B.ld, Cout.p + k0 * Cout.ld, Cout.ld));
-          const int64_t c0 = eff_upper ? k1 : 0, c1 = eff_upper ? K : k0;
-          if (c1 > c0) {
-            // E[k0:k1, c0:c1] = trans ? T[c0:c1, k0:k1]^T : T[k0:k1, c0:c1]
-            const double* Tr = trans ? T.p + c0 + k0 * T.ld : T.p + k0 + c0 * T.ld;
-            CAPITAL_CHECK(capi_dgemm(h, CAPI_NOTRANS, trans, M, c1 - c0, k1 - k0, alpha, B.p + k0 * B.ld, B.ld, Tr, T.ld, 0.0, Cout.p + c0 * Cout.ld, Cout.ld));
+          CAPITAL_CHECK(capi_dgeadd(h, 0, M, N, 0.0, Cout.p, Cout.ld, 0.0, Cout.p, Cout.ld));
+          if (k1 > k0) {
+            const double* Tkk = T.p + k0 + k0 * T.ld;
+            CAPITAL_CHECK(capi_dtrmm_oop(h, side, uplo, trans, diag, M, k1 - k0, alpha, Tkk, T.ld, B.p + k0 * B.ld, B.ld, Cout.p + k0 * Cout.ld, Cout.ld));
+            const int64_t q0 = eff_upper ? k1 : 0, q1 = eff_upper ? K : k0;
+            if (q1 > q0) {
+              // E[k0:k1, q0:q1] = trans ? T[q0:q1, k0:k1]^T : T[k0:k1, q0:q1]
+              const double* Tr = trans ? T.p + q0 + k0 * T.ld : T.p + k0 + q0 * T.ld;
+              CAPITAL_CHECK(capi_dgemm(h, CAPI_NOTRANS, trans, M, q1 - q0, k1 - k0, alpha, B.p + k0 * B.ld, B.ld, Tr, T.ld, 0.0, Cout.p + q0 * Cout.ld, Cout.ld));
+            }
           }
         }
       }
-    } else {
-      const size_t steps = t.d / t.c;
+    } else if (!P.on) {
       for (size_t s = 0; s < steps; ++s) {
         const size_t q = t.z + s * t.c;
         view tt, bb;
@@ -174,8 +222,52 @@ public:
         else { bb = panel(t.row, t.x == q, (int)q, B, ws); tt = panel(t.column, t.y == q, (int)q, T, ws); }
         CAPITAL_CHECK(capi_dtrmm_acc(h, side, uplo, trans, diag, M, N, alpha, tt.p, tt.ld, bb.p, bb.ld, s ? 1.0 : 0.0, Cout.p, Cout.ld));
       }
+    } else {
+      // one K-class (q = z), left multiply: T first, then B column chunk by column chunk on the communication stream
+      const size_t q = t.z;
+      const bool rootB = (t.y == q);
+      P.main(); P.rec(E0);
+      P.comm(); P.wait(E0);
+      view tt = panel(t.row, t.x == q, (int)q, T, ws);
+      P.rec(ET);
+      view bb{nullptr, B.rows, B.rows, B.cols};
+      bb.p = (rootB && B.contiguous()) ? B.p : ws.take(B.count());
+      for (int j = 0; j < nch; ++j) {
+        int64_t c0, c1;
+        chunk_range(N, nch, j, c0, c1);
+        if (c1 > c0) {
+          if (rootB && !B.contiguous()) CAPITAL_CHECK(capi_dlacpy(h, 0, B.rows, c1 - c0, B.p + c0 * B.ld, B.ld, bb.p + c0 * bb.ld, bb.ld));
+          CAPITAL_CHECK(capi_bcast(t.column, bb.p + c0 * bb.ld, bb.rows * (c1 - c0), (int)q));
+        }
+        P.rec(EB + j);
+      }
+      P.main(); P.wait(ET);
+      for (int j = 0; j < nch; ++j) {
+        int64_t c0, c1;
+        chunk_range(N, nch, j, c0, c1);
+        P.wait(EB + j);
+        if (c1 > c0)
+          CAPITAL_CHECK(capi_dtrmm_oop(h, side, uplo, trans, diag, M, c1 - c0, alpha, tt.p, tt.ld, bb.p + c0 * bb.ld, bb.ld, Cout.p + c0 * Cout.ld, Cout.ld));
+        P.rec(EC + j);
+      }
     }
-    if (t.c > 1) allreduce_view(t.depth, Cout, ws);
+    if (t.c > 1) {
+      if (P.on) {
+        P.comm();
+        for (int j = 0; j < nch; ++j) {
+          int64_t c0, c1;
+          chunk_range(N, nch, j, c0, c1);
+          P.wait(EC + j);
+          if (c1 > c0) CAPITAL_CHECK(capi_allreduce_sum(t.depth, Cout.p + c0 * Cout.ld, Cout.rows * (c1 - c0)));
+        }
+        P.rec(ER);
+        P.main(); P.wait(ER);
+      } else {
+        allreduce_view(t.depth, Cout, ws);
+      }
+    } else if (P.on) {
+      P.main();
+    }
     ws.top = mark;
   }
 
@@ -193,30 +285,93 @@ public:
       return;
     }
     const int64_t mark = ws.top;
+    const size_t steps = t.d > 1 ? t.d / t.c : 1;
+    // the pipeline is built for what cholinv issues: upper triangle, transposed form, one K-class per layer
+    const bool piped = t.num_chunks > 0 && trans && uplo == CAPI_UPPER && steps == 1;
+    const int nch = piped ? chunk_count(t.num_chunks, N) : 1;
+    pipe P(piped && nch > 1);
+    enum { E0 = 0, EL = 1, EB = 2, EC = 70, ER = 140 };
     view acc = t.c > 1 ? view{ws.take(N * N), N, N, N} : C;
-    if (t.d == 1) {
-      int64_t k0, k1;
-      kslice(K, t.c, t.z, k0, k1);
-      const view& L = trans ? Bx : A;
-      const view& Rr = trans ? A : Bx;
-      const double* l = trans ? L.p + k0 : L.p + k0 * L.ld;
-      const double* r = trans ? Rr.p + k0 : Rr.p + k0 * Rr.ld;
-      CAPITAL_CHECK(capi_dgemmt(h, uplo, tA, tB, N, k1 - k0, alpha, l, L.ld, r, Rr.ld, 0.0, acc.p, acc.ld));
-    } else {
-      const size_t steps = t.d / t.c;
-      for (size_t s = 0; s < steps; ++s) {
-        const size_t q = t.z + s * t.c;
-        view l, r;
-        if (trans) { l = panel(t.row, t.x == q, (int)q, Bx, ws); r = panel(t.column, t.y == q, (int)q, A, ws); }   // distribute(B,A)
-        else { l = panel(t.row, t.x == q, (int)q, A, ws); r = panel(t.column, t.y == q, (int)q, Bx, ws); }        // distribute(A,B)
-        const double bt = (t.c > 1) ? (s ? 1.0 : 0.0) : (s ? 1.0 : beta);
-        CAPITAL_CHECK(capi_dgemmt(h, uplo, tA, tB, N, K, alpha, l.p, l.ld, r.p, r.ld, bt, acc.p, acc.ld));
+    if (!P.on) {
+      if (t.d == 1) {
+        int64_t k0, k1;
+        kslice(K, t.c, t.z, k0, k1);
+        const view& L = trans ? Bx : A;
+        const view& Rr = trans ? A : Bx;
+        const double* l = trans ? L.p + k0 : L.p + k0 * L.ld;
+        const double* r = trans ? Rr.p + k0 : Rr.p + k0 * Rr.ld;
+        CAPITAL_CHECK(capi_dgemmt(h, uplo, tA, tB, N, k1 - k0, alpha, l, L.ld, r, Rr.ld, 0.0, acc.p, acc.ld));
+      } else {
+        for (size_t s = 0; s < steps; ++s) {
+          const size_t q = t.z + s * t.c;
+          view l, r;
+          if (trans) { l = panel(t.row, t.x == q, (int)q, Bx, ws); r = panel(t.column, t.y == q, (int)q, A, ws); }   // distribute(B,A)
+          else { l = panel(t.row, t.x == q, (int)q, A, ws); r = panel(t.column, t.y == q, (int)q, Bx, ws); }        // distribute(A,B)
+          const double bt = (t.c > 1) ? (s ? 1.0 : 0.0) : (s ? 1.0 : beta);
+          CAPITAL_CHECK(capi_dgemmt(h, uplo, tA, tB, N, K, alpha, l.p, l.ld, r.p, r.ld, bt, acc.p, acc.ld));
+        }
       }
+      if (t.c > 1) {
+        // only the computed triangle is folded into C
+        CAPITAL_CHECK(capi_allreduce_sum(t.depth, acc.p, acc.count()));
+        CAPITAL_CHECK(capi_dgeadd(h, uplo == CAPI_UPPER ? 1 : 2, N, N, 1.0, acc.p, acc.ld, beta, C.p, C.ld));
+      }
+      ws.top = mark;
+      return;
+    }
+    // ---- pipelined: C(upper)[:, chunk] = alpha * L[:, 0:c1]^T * R[:, chunk]; L and R are K x N, k-contiguous
+    int64_t k0 = 0, k1 = K;
+    view l = Bx, r = A;
+    const bool sliced = (t.d == 1);
+    const size_t q = t.z;
+    const bool rootR = sliced || (t.y == q);
+    P.main(); P.rec(E0);
+    P.comm(); P.wait(E0);
+    if (sliced) {
+      kslice(K, t.c, t.z, k0, k1);
+    } else {
+      l = panel(t.row, t.x == q, (int)q, Bx, ws);
+      r = view{(rootR && A.contiguous()) ? A.p : ws.take(A.count()), A.rows, A.rows, A.cols};
+    }
+    P.rec(EL);
+    for (int j = 0; j < nch; ++j) {
+      int64_t c0, c1;
+      chunk_range(N, nch, j, c0, c1);
+      if (!sliced && c1 > c0) {
+        if (rootR && !A.contiguous()) CAPITAL_CHECK(capi_dlacpy(h, 0, A.rows, c1 - c0, A.p + c0 * A.ld, A.ld, r.p + c0 * r.ld, r.ld));
+        CAPITAL_CHECK(capi_bcast(t.column, r.p + c0 * r.ld, r.rows * (c1 - c0), (int)q));
+      }
+      P.rec(EB + j);
+    }
+    P.main(); P.wait(EL);
+    if (t.c > 1) capital::dev_zero(acc.p, acc.count());       // whole columns are summed over depth below
+    const double bt = t.c > 1 ? 0.0 : beta;
+    for (int j = 0; j < nch; ++j) {
+      int64_t c0, c1;
+      chunk_range(N, nch, j, c0, c1);
+      P.wait(EB + j);
+      if (c1 > c0) {
+        const double* rj = r.p + k0 + c0 * r.ld;
+        if (c0 > 0)   // rows above the diagonal block of this chunk: a plain rectangle
+          CAPITAL_CHECK(capi_dgemm(h, CAPI_TRANS, CAPI_NOTRANS, c0, c1 - c0, k1 - k0, alpha, l.p + k0, l.ld, rj, r.ld, bt, acc.p + c0 * acc.ld, acc.ld));
+        CAPITAL_CHECK(capi_dgemmt(h, CAPI_UPPER, CAPI_TRANS, CAPI_NOTRANS, c1 - c0, k1 - k0, alpha, l.p + k0 + c0 * l.ld, l.ld, rj, r.ld, bt,
+                                  acc.p + c0 + c0 * acc.ld, acc.ld));
+      }
+      P.rec(EC + j);
     }
     if (t.c > 1) {
-      // only the computed triangle is summed over depth and folded into C
-      CAPITAL_CHECK(capi_allreduce_sum(t.depth, acc.p, acc.count()));
-      CAPITAL_CHECK(capi_dgeadd(h, uplo == CAPI_UPPER ? 1 : 2, N, N, 1.0, acc.p, acc.ld, beta, C.p, C.ld));
+      P.comm();
+      for (int j = 0; j < nch; ++j) {
+        int64_t c0, c1;
+        chunk_range(N, nch, j, c0, c1);
+        P.wait(EC + j);
+        if (c1 > c0) CAPITAL_CHECK(capi_allreduce_sum(t.depth, acc.p + c0 * acc.ld, acc.rows * (c1 - c0)));
+      }
+      P.rec(ER);
+      P.main(); P.wait(ER);
+      CAPITAL_CHECK(capi_dgeadd(h, 1, N, N, 1.0, acc.p, acc.ld, beta, C.p, C.ld));
+    } else {
+      P.main();
     }
     ws.top = mark;
   }

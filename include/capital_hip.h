@@ -155,6 +155,14 @@ int capi_reduce_sum(capi_comm_t c, const double* send, double* recv, int64_t cou
 int capi_allgather(capi_comm_t c, const double* send, double* recv, int64_t count_per_rank);   /* MPI_Allgather, policy.h:176 */
 int capi_sendrecv_replace(capi_comm_t c, double* buf, int64_t count, int peer, double* staging); /* MPI_Sendrecv_replace, util.hpp:240 */
 
+/* ---- second stream + events: lets the host layer run collectives beside the tile kernel (the reference's
+ *      MPI_Ibcast/Iallreduce chunk pipeline, summa.hpp:195-215,238-249).  capi_stream_select(h, 1) routes every
+ *      following call on this handle (kernels, copies, collectives) to the handle's communication stream, 0 back to
+ *      the compute stream; events order work across the two (slot in [0, 1024)). ---- */
+int capi_stream_select(capi_handle_t h, int which);
+int capi_event_record(capi_handle_t h, int slot);   /* on the currently selected stream */
+int capi_event_wait(capi_handle_t h, int slot);     /* the currently selected stream waits for that record */
+
 /* ---- measurement helpers ---- */
 /* register-resident v_mfma_f64_16x16x4_f64 loop on every CU: returns achieved TFLOP/s (synchronous) */
 int capi_mfma_f64_peak(capi_handle_t h, int iters, double* tflops);

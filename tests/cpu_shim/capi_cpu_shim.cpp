@@ -245,6 +245,10 @@ int capi_sendrecv_replace(capi_comm_t c, double* buf, int64_t count, int peer, d
   return coll(c, 4, buf, nullptr, count, peer);
 }
 
+// one host thread executes everything in program order: streams and events are no-ops
+int capi_stream_select(capi_handle_t, int) { return 0; }
+int capi_event_record(capi_handle_t, int) { return 0; }
+int capi_event_wait(capi_handle_t, int) { return 0; }
 int capi_prof_enable(capi_handle_t, int) { return 0; }
 int capi_prof_collect(capi_handle_t, int, int64_t* l, double* ms, double* fl, double* mx) { *l = 0; *ms = 0; *fl = 0; if (mx) *mx = 0; return 0; }
 int capi_mfma_f64_peak(capi_handle_t, int, double* t) { *t = 0; return 0; }

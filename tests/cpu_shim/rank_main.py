@@ -108,7 +108,7 @@ def main():
     out = {"rank": rank}
     if cfg["kind"] == "cholinv":
         p = driver.Cholinv(cfg["n"], c=cfg["c"], complete_inv=cfg["ci"], split=cfg.get("split", 1), bc_mult=cfg["bc"],
-                           layout=cfg.get("layout", 0), serialize=cfg["serialize"], bc_policy=cfg["policy"])
+                           layout=cfg.get("layout", 0), num_chunks=cfg.get("chunks", 0), serialize=cfg["serialize"], bc_policy=cfg["policy"])
         p.generate()
         p.factor()
         res = p.residual()

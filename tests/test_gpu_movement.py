@@ -127,3 +127,28 @@ def test_diff_norms(hip, oracle):
     i, j = np.indices((m, n))
     sel = i <= j
     assert abs(out[0] - ((X - Y)[sel] ** 2).sum()) <= 1e-10 and abs(out[1] - (Y[sel] ** 2).sum()) <= 1e-10
+
+
+def test_two_streams_and_events(hip, oracle):
+    """capi_stream_select / capi_event_record / capi_event_wait: work issued on the communication stream is ordered
+    against the compute stream only through events (the chunked SUMMA pipeline relies on exactly this)."""
+    import torch
+    from capital_amd import capi
+    n = 1 << 22
+    x = torch.ones(n, dtype=torch.float64, device="cuda")
+    y = torch.zeros(n, dtype=torch.float64, device="cuda")
+    z = torch.zeros(n, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    for rep in range(3):
+        hip.call("capi_daxpby", n, 1.0, capi.ptr(x), capi.ptr(y))          # compute stream: y += x
+        hip.call("capi_event_record", 0)
+        hip.call("capi_stream_select", 1)
+        hip.call("capi_event_wait", 0)
+        hip.call("capi_daxpby", n, 0.0, capi.ptr(y), capi.ptr(z))          # comm stream: z = y (must see the update)
+        hip.call("capi_event_record", 1)
+        hip.call("capi_stream_select", 0)
+        hip.call("capi_event_wait", 1)
+        hip.call("capi_daxpby", n, 1.0, capi.ptr(z), capi.ptr(y))          # compute stream: y += z
+    hip.sync()
+    # y: 1 -> 2 | 3 -> 6 | 7 -> 14 ; z follows y before the doubling
+    assert float(y[0]) == 14.0 and float(y[-1]) == 14.0 and float(z[12345]) == 7.0

@@ -35,7 +35,7 @@ def _launch(world, cfg, timeout=600):
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   OMP_NUM_THREADS="1", GLOO_SOCKET_IFNAME="lo")
+                   OMP_NUM_THREADS="1", GLOO_SOCKET_IFNAME="lo", CAPITAL_MIN_CHUNK_COLS="8")
         procs.append(subprocess.Popen([sys.executable, os.path.join(SHIM, "rank_main.py"), json.dumps(cfg)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -53,6 +53,10 @@ def _launch(world, cfg, timeout=600):
 # (world, c) -> d x d x c grids: 2 = 1x1x2 (K-slicing), 4 = 2x2x1 (two K-classes per layer), 8 = 2x2x2 (the reference's cubic case)
 @pytest.mark.parametrize("world,c,n,bc,ci,serialize,policy", [
     (2, 2, 96, -2, 1, False, 0),
+    (2, 2, 160, -2, 1, False, (0, 3)),   # (policy, num_chunks): chunked / overlapped SUMMA pipeline, K-sliced grid
+    (8, 2, 192, -2, 1, True, (0, 3)),    # same on the cubic grid
+    (8, 2, 200, -1, 0, False, (2, 5)),
+    (4, 1, 128, -1, 1, False, (0, 4)),   # two K-classes per layer: pipeline must stay off, results unchanged
     (2, 2, 128, -1, 0, True, 2),
     (4, 1, 128, -1, 1, False, 0),
     (4, 1, 97, -2, 0, True, 1),        # grid does not divide n: padding path
@@ -61,8 +65,11 @@ def _launch(world, cfg, timeout=600):
     (8, 2, 130, 0, 1, True, 3),
 ])
 def test_cholinv_on_grids(oracle, shim_lib, world, c, n, bc, ci, serialize, policy):
+    chunks = 0
+    if isinstance(policy, tuple):
+        policy, chunks = policy
     with tempfile.TemporaryDirectory() as d:
-        _launch(world, {"kind": "cholinv", "n": n, "c": c, "bc": bc, "ci": ci, "serialize": serialize, "policy": policy, "dir": d})
+        _launch(world, {"kind": "cholinv", "n": n, "c": c, "bc": bc, "ci": ci, "serialize": serialize, "policy": policy, "chunks": chunks, "dir": d})
         A = oracle.distribute_symmetric(n, n, 0, 0, 1, 1)
         Rg, Ig = np.zeros((n, n), order="F"), np.zeros((n, n), order="F")
         levels = set()

@@ -60,7 +60,7 @@ public:
                       std::is_same<typename MatrixCType::StructureType, rect>::value,
                   "summa gemm works on rect blocks (the reference's callers only pass rect: cacqr.hpp:62, validate.hpp)");
     arena& ws = scratch_arena();
-    ws.reserve(2 * (A.num_elems() + B.num_elems() + C.num_elems()) + 64);
+    if (!(CommInfo.d == 1 && CommInfo.c == 1)) ws.reserve(2 * (A.num_elems() + B.num_elems() + C.num_elems()) + 64);
     gemm(CommInfo, (int)pack.transposeA, (int)pack.transposeB, pack.alpha, as_view(A), as_view(B), pack.beta, as_view(C), ws);
   }
   // B <- alpha * op(A) * B  or  alpha * B * op(A), A triangular (summa.hpp:46-83)

@@ -16,11 +16,16 @@ public:
     if (args.dir != 'U') throw std::invalid_argument("validate: only dir == 'U' (cholinv.hpp:9)");
     auto R = AlgType::construct_R(args, CommInfo);
     util::remove_triangle(R, CommInfo.x, CommInfo.y, CommInfo.d, args.dir);      // validate.hpp:11
-    auto RT = R;
-    util::transpose(RT, CommInfo);                                               // validate.hpp:13
     MatrixType P(A.num_columns_global(), A.num_rows_global(), CommInfo.d, CommInfo.d);
     blas::ArgPack_gemm<T> gemmArgs(blas::Order::AblasColumnMajor, blas::Transpose::AblasTrans, blas::Transpose::AblasNoTrans, 1., 0.);
-    matmult::summa::invoke(RT, R, P, CommInfo, gemmArgs);                         // validate.hpp:35
+    if (CommInfo.d == 1) {
+      // the partner exchange is the identity on a 1 x 1 slice: no second copy of a block that may be 32 GiB
+      matmult::summa::invoke(R, R, P, CommInfo, gemmArgs);
+    } else {
+      auto RT = R;
+      util::transpose(RT, CommInfo);                                             // validate.hpp:13
+      matmult::summa::invoke(RT, R, P, CommInfo, gemmArgs);                       // validate.hpp:35
+    }
     return util::residual_local(P, A, 0, CommInfo.slice, CommInfo.x, CommInfo.y, CommInfo.d, CommInfo.d);
   }
 };

@@ -55,6 +55,7 @@ struct GemmArgs {
   int64_t slab_ld, slab_stride;
   int tiles_m, tiles_n, ntiles;
   int ts;             // tile size chosen by the launcher
+  int stagger;        // cycles/64 by which odd-numbered co-resident workgroups delay their start (0 = off)
   int no_skip;        // diagnostics: never skip zero sub-tiles
   int share_ab;       // A and B are the same matrix in the same orientation (syrk): diagonal tiles stage ONE panel
 };
@@ -227,6 +228,17 @@ __global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel
   const int lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, g = lane >> 4;
   const int wm = wave & 1, wn = wave >> 1;
+
+  // Two workgroups share a CU (one wave of each per SIMD) and run the same program at the same rate: started together
+  // they stay in lockstep, so their load/staging phases (no MFMA) coincide and the matrix pipe idles in both at once.
+  // The workgroup that got the odd threadgroup slot of its CU starts half a panel late; the offset then persists.
+  if (p.stagger > 0) {
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    if ((hwid >> 16) & 1) {
+      for (int i = 0; i < p.stagger; i += 64) __builtin_amdgcn_s_sleep(64);
+    }
+  }
 
   // XCD-aware re-deal: consecutive pids share an XCD (dispatcher deals blockIdx round-robin over 8 XCDs)
   const int nblk = gridDim.x, bid = blockIdx.x;
@@ -474,6 +486,7 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
   p.a_vec = (((uintptr_t)p.A & 15) == 0) && ((p.lda & 1) == 0);
   p.b_vec = (((uintptr_t)p.B & 15) == 0) && ((p.ldb & 1) == 0);
   p.no_skip = getenv("CAPI_NO_SKIP") ? 1 : 0;
+  p.stagger = getenv("CAPI_STAGGER") ? atoi(getenv("CAPI_STAGGER")) : 0;
   p.share_ab = (p.out_uplo >= 0 && p.A == p.B && p.lda == p.ldb && ak == bkc && !getenv("CAPI_NO_SHARE")) ? 1 : 0;
   p.splitk = 1;
   p.k_per_split = p.K;

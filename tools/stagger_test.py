@@ -1,0 +1,20 @@
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from capital_amd import capi
+h = capi.Handle(0)
+n = 8192
+A = torch.rand((n, n), dtype=torch.float64, device="cuda") - 0.5
+B = torch.rand((n, n), dtype=torch.float64, device="cuda") - 0.5
+Cm = torch.zeros((n, n), dtype=torch.float64, device="cuda")
+def timeit(fn, reps=4):
+    fn(); h.sync()
+    ms = C.c_float(); best = 1e9
+    for _ in range(reps):
+        h.call("capi_timer_start"); fn(); h.call("capi_timer_stop_ms", C.byref(ms)); best = min(best, ms.value)
+    return best
+for rnd in range(2):
+    for st in (0, 64, 128, 256, 0):
+        os.environ["CAPI_STAGGER"] = str(st)
+        t = timeit(lambda: h.call("capi_dgemm", 1, 0, n, n, n, 1.0, capi.ptr(A), n, capi.ptr(B), n, 0.0, capi.ptr(Cm), n))
+        print(f"stagger={st*1}: gemm TN 8192 {2*n**3/t/1e9:.2f} TF/s", flush=True)

@@ -390,7 +390,6 @@ public:
     k1 = std::min<int64_t>(K, k0 + per);
   }
 
-private:
   // The panel a rank multiplies with: the root's own block (packed to contiguous if it is a strided view) broadcast
   // over `comm`.  Non-roots receive into arena memory.  Blocks have equal shapes on all ranks of a communicator.
   static view panel(capi_comm_t comm, bool is_root, int root, const view& mine, arena& ws) {

@@ -2,8 +2,8 @@
 // (reference src/alg/qr/cacqr/cacqr.h:13-78, cacqr.hpp:7-29,174-193,219-270).
 //
 // Same call surface: cacqr<SerializePolicy,IntermediatesPolicy>::factor(A, args, rectTopo), construct_Q / construct_R,
-// info<T,U,CholeskyInversionType>(num_iter, ci_args).  The 1-D variant (c == 1, BASELINE configs 3 and 5) is the hot
-// path; per sweep (cacqr.hpp:7-29):
+// info<T,U,CholeskyInversionType>(num_iter, ci_args).  c == 1 is the 1-D variant (BASELINE configs 3 and 5, the hot path);
+// c == d is the 3-D variant on a cubic grid (sweep_3d below).  1-D, per sweep (cacqr.hpp:7-29):
 //     K7  G = Q^T Q            capi_dsyrk, split-K over the tall dimension, upper triangle only
 //     C8  G = sum over ranks   capi_allreduce_sum over `world` (packed n(n+1)/2 doubles with Serialize)
 //     K8+K9  R = chol(G), R^-1 capi_dpotrf_trtri, replicated on every GPU
@@ -53,9 +53,13 @@ public:
     const auto gN = A.num_columns_global(), gM = A.num_rows_global();
     args.Q._register_(gN, gM, CommInfo.c, CommInfo.d);
     args.R._register_(gN, gN, CommInfo.c, CommInfo.c);
-    if (CommInfo.c != 1)
-      throw std::logic_error("qr::cacqr: the 3-D / tunable-grid sweeps (cacqr.hpp:75-170, c > 1) are the next row of the scope table and are not built yet; use c == 1");
-    invoke_1d(A, args, CommInfo);
+    if (CommInfo.c == 1) {
+      invoke_1d(A, args, CommInfo);
+    } else if (CommInfo.c == CommInfo.d) {
+      invoke_3d(A, args, CommInfo);
+    } else {
+      throw std::logic_error("qr::cacqr: the tunable c x d x c sweep (cacqr.hpp:124-170, 1 < c < d) needs c*c*d > 8 GPUs and is not built; use c == 1 or c == d");
+    }
     if (!IP::keep_work) { args.G._destroy_(); args.Ginv._destroy_(); args.R1._destroy_(); args.Gpacked._destroy_(); }
   }
 
@@ -116,6 +120,63 @@ protected:
     } else {
       finalize_R(args.G, args, n);   // the reference leaves the Gram matrix in R here with Serialize; R is what is documented
     }
+  }
+
+  // ---- 3-D variant, c == d (cacqr.hpp:75-116 sweep_3d, :195-215 invoke_3d) ---------------------------------------------
+  // Gram matrix by SUMMA-style exchange: the A block of the row-root (x == z) is broadcast along `row`, multiplied with
+  // the local block, the partial Grams are reduced over `column` onto (y == z) and broadcast over `depth` from y:
+  // every rank ends with the element-cyclic (x,y) block of G = A^T A, replicated over z -- the input format of cholinv.
+  template <typename Sq, typename ArgType>
+  static void sweep_3d(const double* src, double* dst, int64_t m_loc, int64_t n_loc, ArgType& args, Sq& sq, matmult::arena& ws,
+                       matrix<double, int64_t, rect>& G) {
+    using CI = typename std::remove_reference<ArgType>::type::cholesky_inverse_type;
+    capi_handle_t h = capital::handle();
+    const int64_t mark = ws.top;
+    matmult::view Aloc{const_cast<double*>(src), m_loc, m_loc, n_loc};
+    CRITTER_START(CQR::gram);
+    matmult::view Abc = matmult::summa::panel(sq.row, sq.x == sq.z, (int)sq.z, Aloc, ws);                           // C9 Bcast(row)
+    double* part = ws.take(n_loc * n_loc);
+    CAPITAL_CHECK(capi_dgemm(h, CAPI_TRANS, CAPI_NOTRANS, n_loc, n_loc, m_loc, 1.0, Abc.p, Abc.ld, src, m_loc, 0.0, part, n_loc));   // K3
+    double* red = ws.take(n_loc * n_loc);
+    CAPITAL_CHECK(capi_reduce_sum(sq.column, part, red, n_loc * n_loc, (int)sq.z));                                   // C9 Reduce(column)
+    double* gsrc = (sq.y == sq.z) ? red : part;    // the depth root (z == y) holds the reduced block; others receive into `part`
+    CAPITAL_CHECK(capi_bcast(sq.depth, gsrc, n_loc * n_loc, (int)sq.y));                                              // C9 Bcast(depth)
+    capital::dev_copy(G.data(), gsrc, n_loc * n_loc);
+    CRITTER_STOP(CQR::gram);
+    CRITTER_START(CQR::formR);
+    CI::factor(G, args.cholesky_inverse_args, sq);                                                                   // cacqr.hpp:103
+    if (!args.cholesky_inverse_args.complete_inv)
+      throw std::logic_error("qr::cacqr 3-D: the blocked solve() for complete_inv == 0 (cacqr.hpp:44-73) is not built; pass complete_inv = 1");
+    auto Rinv = CI::construct_Rinv(args.cholesky_inverse_args, sq);
+    matmult::view Tv{Rinv.data(), n_loc, n_loc, n_loc}, Cv{dst, m_loc, m_loc, n_loc};
+    matmult::summa::trmm(sq, CAPI_RIGHT, CAPI_UPPER, CAPI_NOTRANS, CAPI_NONUNIT, 1.0, Tv, Aloc, Cv, ws);               // cacqr.hpp:108-112
+    capital::sync();   // Rinv (a temporary) must outlive the multiply
+    CRITTER_STOP(CQR::formR);
+    ws.top = mark;
+  }
+
+  template <typename MatrixType, typename ArgType, typename CommType>
+  static void invoke_3d(const MatrixType& A, ArgType& args, CommType&& CommInfo) {
+    using CI = typename std::remove_reference<ArgType>::type::cholesky_inverse_type;
+    topo::square sq(CommInfo.cube, CommInfo.c, CommInfo.layout, CommInfo.num_chunks);
+    const int64_t n = A.num_columns_global(), n_loc = A.num_columns_local(), m_loc = A.num_rows_local();
+    matrix<double, int64_t, rect> G(n, n, CommInfo.c, CommInfo.c);
+    matmult::arena& ws = matmult::summa::scratch_arena();
+    ws.reserve(6 * m_loc * n_loc + 8 * n_loc * n_loc + 1024);
+    sweep_3d(A.data(), args.Q.data(), m_loc, n_loc, args, sq, ws, G);
+    matrix<double, int64_t, rect> Rfinal = CI::construct_R(args.cholesky_inverse_args, sq);
+    if (args.num_iter > 1) {
+      matrix<double, int64_t, rect> R1 = Rfinal;                                                                     // save_R_3d
+      sweep_3d(args.Q.data(), args.Q.scratch(), m_loc, n_loc, args, sq, ws, G);
+      args.Q.swap();
+      matrix<double, int64_t, rect> R2 = CI::construct_R(args.cholesky_inverse_args, sq);
+      // R = R2 * R1 on the grid (cacqr.hpp:208-211): right multiply by the triangular R1
+      matmult::view Tv{R1.data(), n_loc, n_loc, n_loc}, Bv{R2.data(), n_loc, n_loc, n_loc}, Cv{Rfinal.data(), n_loc, n_loc, n_loc};
+      matmult::summa::trmm(sq, CAPI_RIGHT, CAPI_UPPER, CAPI_NOTRANS, CAPI_NONUNIT, 1.0, Tv, Bv, Cv, ws);
+      capital::sync();
+    }
+    serialize<uppertri, uppertri>::invoke(Rfinal, args.R, 0, n_loc, 0, n_loc, 0, n_loc, 0, n_loc);                    // cacqr.hpp:214
+    capital::sync();
   }
 
   template <typename ArgType>

@@ -116,10 +116,13 @@ def main():
                  residual=res, stats=np.array(list(p.stats().values())))
         p.close()
     else:
-        q = driver.Cacqr(cfg["m"], cfg["n"], c=1, variant=cfg["variant"], serialize=cfg["serialize"])
+        q = driver.Cacqr(cfg["m"], cfg["n"], c=cfg.get("c", 1), variant=cfg["variant"], complete_inv=cfg.get("ci", 0), bc_mult=cfg.get("bc", 0),
+                         serialize=cfg["serialize"])
         q.generate()
         q.factor()
-        np.savez(os.path.join(cfg["dir"], f"rank{rank}.npz"), A=q.A(), Q=q.Q(), R=q.R(), residual=q.residual(), orth=q.orthogonality())
+        c3 = cfg.get("c", 1)
+        np.savez(os.path.join(cfg["dir"], f"rank{rank}.npz"), A=q.A(), Q=q.Q(), R=q.R(),
+                 residual=q.residual() if c3 == 1 else -1.0, orth=q.orthogonality() if c3 == 1 else -1.0)
         q.close()
     lib.capital_drv_finalize()
     dist.barrier()

@@ -127,3 +127,27 @@ def test_cacqr_1d_sharded_rows(oracle, shim_lib, world, m, n, variant, serialize
         assert info == 0
         assert np.abs(Rs[0] - Rref).max() <= 1e-12 * np.abs(Rref).max()
         assert np.abs(Qg - Qref).max() <= 1e-12 * (1 if variant == 2 else 100)
+
+
+@pytest.mark.parametrize("m,n,variant,serialize,bc", [(512, 32, 2, False, 0), (1000, 48, 2, True, -1), (512, 32, 1, False, 0)])
+def test_cacqr_3d_cubic_grid(oracle, shim_lib, m, n, variant, serialize, bc):
+    """c == d == 2 on 8 ranks (cacqr.hpp:75-116,195-215): Gram by Bcast(row)+gemm+Reduce(column)+Bcast(depth), distributed
+    cholinv on the Gram matrix, Q = Q R^-1 by a right-TRMM SUMMA.  Q and R are unique, so the assembled result must equal
+    the 1-D oracle on the assembled input."""
+    world, c, d = 8, 2, 2
+    with tempfile.TemporaryDirectory() as dd:
+        _launch(world, {"kind": "cacqr", "m": m, "n": n, "c": c, "variant": variant, "serialize": serialize, "ci": 1, "bc": bc, "dir": dd})
+        Ag, Qg, Rg = np.zeros((m, n), order="F"), np.zeros((m, n), order="F"), np.zeros((n, n), order="F")
+        for r in range(world):
+            z = np.load(os.path.join(dd, f"rank{r}.npz"))
+            x, y, zz = (r % (c * c)) // c, r // (c * c), r % c            # topology.h:46-50
+            np.testing.assert_array_equal(z["A"], oracle.distribute_random(n, m, x, y, c, d, key=r // c))
+            if zz == 0:
+                oracle.cyclic_insert(Ag, np.asfortranarray(z["A"]), x, y, c, d)
+                oracle.cyclic_insert(Qg, np.asfortranarray(z["Q"]), x, y, c, d)
+                oracle.cyclic_insert(Rg, np.asfortranarray(z["R"]), x, y, c, c)
+        Qref, Rref, info = oracle.cacqr_factor_1d(Ag, 1, variant)
+        assert info == 0
+        assert np.abs(Rg - Rref).max() <= 1e-12 * np.abs(Rref).max()
+        assert np.abs(Qg - Qref).max() <= 1e-12 * (1 if variant == 2 else 100)
+        assert oracle.qr_orthogonality(Qg) <= (1e-15 if variant == 2 else 1e-12)

@@ -206,21 +206,27 @@ __global__ __launch_bounds__(256, 1) void potrf_trtri_leaf_kernel(double* __rest
 typedef double d4l_t __attribute__((ext_vector_type(4)));
 constexpr int LB = 128, LLD = 130, LNT = 8;
 
+// GIVEN: the tile already holds a finished triangular factor U (inverse-only calls); only V = U^-T is formed.
+// Branch-free per-step body (selects instead of exec-mask branches) and a rolled loop: the fully unrolled, branchy form
+// spent ~150 instructions and several SGPR spills per step on what is a ~40-instruction dependency chain.
+template <bool GIVEN>
 __device__ __forceinline__ void leaf_diag(double* __restrict__ M, double* __restrict__ Vs, double (*rowU)[16], double (*rowW)[16],
-                                          int k, int tid, bool given, bool unit, int* __restrict__ info, int info_base, int b) {
+                                          int k, int tid, bool unit, int* __restrict__ info, int info_base, int b) {
   const int i = tid & 15, j = tid >> 4, k0 = 16 * k;
   double a = M[(k0 + i) + (k0 + j) * LLD];
   if (i > j) a = 0.0;
-  if (given && unit && i == j) a = 1.0;
+  if (GIVEN && unit && i == j) a = 1.0;
   double w = 0.0;                       // accumulates sum_m U[m][i] V[m][j], becomes V[i][j] (j <= i)
   if (i == 0) { rowU[0][j] = a; rowW[0][j] = 0.0; }
   __syncthreads();
+#pragma nounroll
   for (int s = 0; s < 16; ++s) {
     const int cur = s & 1;
     double p = rowU[cur][s];
+    const double ui = rowU[cur][i], uj = rowU[cur][j], wj = rowW[cur][j];
     double y, sq;
-    if (given) {
-      if (p == 0.0) p = 1.0;
+    if (GIVEN) {
+      p = p == 0.0 ? 1.0 : p;
       y = 1.0 / p;                      // row s of U is final: y = 1/u_ss
       sq = p;
     } else {
@@ -234,17 +240,16 @@ __device__ __forceinline__ void leaf_diag(double* __restrict__ M, double* __rest
       sq = p * y;
       sq = sq + 0.5 * y * (p - sq * sq);
     }
-    const double ui = rowU[cur][i], uj = rowU[cur][j];
-    const double vsj = j <= s ? ((j == s ? 1.0 : 0.0) - rowW[cur][j]) * y : 0.0;     // V[s][j]
-    const double usi = given ? ui : ui * y;                                           // U[s][i]
-    if (i > s) {
-      if (!given && i <= j) a -= ui * uj * (y * y);
-      w += usi * vsj;
-    } else if (i == s) {
-      if (!given) a = j > s ? uj * y : (j == s ? sq : 0.0);
-      w = vsj;
+    const bool gt = i > s, eq = i == s;
+    const double vsj = j <= s ? ((j == s ? 1.0 : 0.0) - wj) * y : 0.0;               // V[s][j]
+    const double usi = GIVEN ? ui : ui * y;                                           // U[s][i]
+    if (!GIVEN) {
+      const double upd = a - ui * uj * (y * y);
+      const double fin = j > s ? uj * y : (j == s ? sq : 0.0);
+      a = eq ? fin : ((gt && i <= j) ? upd : a);
     }
-    if (s + 1 < 16 && i == s + 1) { rowU[cur ^ 1][j] = a; rowW[cur ^ 1][j] = w; }
+    w = eq ? vsj : (gt ? w + usi * vsj : w);
+    if (i == s + 1) { rowU[cur ^ 1][j] = a; rowW[cur ^ 1][j] = w; }
     __syncthreads();
   }
   M[(k0 + i) + (k0 + j) * LLD] = i <= j ? a : 0.0;
@@ -277,7 +282,8 @@ __global__ __launch_bounds__(256, 1) void potrf_trtri_leaf128_kernel(double* __r
   __syncthreads();
 
   for (int k = 0; k < nk; ++k) {
-    leaf_diag(M, Vs, rowU, rowW, k, tid, invert_only != 0, unit != 0, info, info_base, b);
+    if (invert_only) leaf_diag<true>(M, Vs, rowU, rowW, k, tid, unit != 0, info, info_base, b);
+    else leaf_diag<false>(M, Vs, rowU, rowW, k, tid, false, info, info_base, b);
     __syncthreads();
     if (invert_only || k + 1 >= nk) continue;
     const int k0 = 16 * k;

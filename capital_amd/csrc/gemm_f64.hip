@@ -204,9 +204,12 @@ __device__ __forceinline__ void tile_of(const GemmArgs& p, int t, int& ti, int& 
     const int loc = t - group * in_group;
     const int a = first_m + loc % gsz;
     int b = loc / gsz;
-    // a TRMM tile's k-range grows linearly along b: pair short with long so that every contiguous chunk of ids (an
-    // XCD's share, or what a CU sees over time) carries the average amount of work
-    if (p.tri_side >= 0) b = (b & 1) ? nn - 1 - (b >> 1) : (b >> 1);
+    // a TRMM tile's k-range grows or shrinks linearly along b: issue the long ones first (longest-processing-time
+    // order inside each XCD's share; every share holds all values of b, so the shares stay balanced)
+    if (p.tri_side >= 0) {
+      const bool grows = (p.tri_side == CAPI_LEFT) ? !p.tri_eff_upper : (p.tri_eff_upper != 0);
+      if (grows) b = nn - 1 - b;
+    }
     ti = by_cols ? b : a;
     tj = by_cols ? a : b;
   } else {
@@ -232,11 +235,11 @@ __global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel
   // Two workgroups share a CU (one wave of each per SIMD) and run the same program at the same rate: started together
   // they stay in lockstep, so their load/staging phases (no MFMA) coincide and the matrix pipe idles in both at once.
   // The workgroup that got the odd threadgroup slot of its CU starts half a panel late; the offset then persists.
-  if (p.stagger > 0) {
+  if ((p.stagger & 1023) > 0) {
     unsigned hwid;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
     if ((hwid >> 16) & 1) {
-      for (int i = 0; i < p.stagger; i += 64) __builtin_amdgcn_s_sleep(64);
+      for (int i = 0; i < (p.stagger & 1023); i += 64) __builtin_amdgcn_s_sleep(64);
     }
   }
 
@@ -348,8 +351,10 @@ __global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel
       for (int a = 0; a < SUB; ++a) af[a] = frag_read<TS, AK>(La, wm * (TS / 2) + a * 16 + r16, u, g);
 #pragma unroll
       for (int b = 0; b < SUB; ++b) bf[b] = frag_read<TS, BKC>(Lb, wn * (TS / 2) + b * 16 + r16, u, g);
+      __builtin_amdgcn_s_setprio(1);      // keeps the cluster contiguous (+1 % measured)
       mfma_step<SUB, 0>(acc, af, bf, keep);
       mfma_step<SUB, 1>(acc, af, bf, keep);
+      __builtin_amdgcn_s_setprio(0);
     }
     if (more) {
       if (maskA && kn < i0 + BM && kn + BK > i0) panel_mask<TS, AK>(i0, kn, tid, keep_ge, p.tri_unit, ra);

@@ -14,7 +14,8 @@ def timeit(fn, reps=4):
         h.call("capi_timer_start"); fn(); h.call("capi_timer_stop_ms", C.byref(ms)); best = min(best, ms.value)
     return best
 for rnd in range(2):
-    for st in (0, 64, 128, 256, 0):
+    for st in (0, 1024, 0, 1024):
         os.environ["CAPI_STAGGER"] = str(st)
         t = timeit(lambda: h.call("capi_dgemm", 1, 0, n, n, n, 1.0, capi.ptr(A), n, capi.ptr(B), n, 0.0, capi.ptr(Cm), n))
-        print(f"stagger={st*1}: gemm TN 8192 {2*n**3/t/1e9:.2f} TF/s", flush=True)
+        t2 = timeit(lambda: h.call("capi_dtrmm_oop", 0, 1, 1, 0, n, n, 1.0, capi.ptr(A), n, capi.ptr(B), n, capi.ptr(Cm), n))
+        print(f"setprio={st//1024}: gemm TN 8192 {2*n**3/t/1e9:.2f} TF/s   trmm LUT {n**3/t2/1e9:.2f} TF/s", flush=True)

@@ -19,6 +19,7 @@
 //   * workgroup ids are re-dealt so that the 64 tiles an XCD runs concurrently form a compact block
 //     of the output (8 XCDs x private 4 MiB L2).
 #include "capi_internal.h"
+#include <type_traits>
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
 typedef double d2_t __attribute__((ext_vector_type(2)));
@@ -307,21 +308,24 @@ __global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel
   }
   __syncthreads();
 
-  for (int t = 0; t < ntk; ++t) {
+  // One iteration = prefetch panel t+1 into registers, MFMA over panel t from LDS, stage panel t+1, barrier.
+  // FAST iterations (interior tile, successor panel entirely in range) are a loop of their own: sharing one loop with
+  // the predicated loads made the register allocator keep two copies of the staging registers and wait for the
+  // prefetch (s_waitcnt vmcnt) BEFORE the MFMA phase to reconcile them -- the load latency it was meant to hide.
+  auto iterate = [&](const int t, auto fast_tag) {
+    constexpr bool FAST = decltype(fast_tag)::value;
     const double* La = lds + (t & 1) * STAGE_LDS;
     const double* Lb = shareB ? La : La + TILE_LDS;
     const int kn = klo + (t + 1) * BK;
-    const bool more = (t + 1 < ntk);
-    if (more) {
+    const bool more = FAST || (t + 1 < ntk);
+    if (FAST) {
       fa += ksa;
       fb += ksb;
-      if (interior && kn + BK <= khi) {
-        panel_load_fast<TS>(fa, qsa, ra);
-        if (!shareB) panel_load_fast<TS>(fb, qsb, rb);
-      } else {
-        panel_load<TS, AK>(p.A, p.lda, i0, p.M, kn, khi, tid, p.a_vec, ra);
-        if (!shareB) panel_load<TS, BKC>(p.B, p.ldb, j0, p.N, kn, khi, tid, p.b_vec, rb);
-      }
+      panel_load_fast<TS>(fa, qsa, ra);
+      panel_load_fast<TS>(fb, qsb, rb);       // (on a shared diagonal tile this re-reads A's panel: cache hit, never staged)
+    } else if (more) {
+      panel_load<TS, AK>(p.A, p.lda, i0, p.M, kn, khi, tid, p.a_vec, ra);
+      if (!shareB) panel_load<TS, BKC>(p.B, p.ldb, j0, p.N, kn, khi, tid, p.b_vec, rb);
     }
     // sub-tile activity of this wave for this panel (wave-uniform)
     unsigned keep = out_keep;
@@ -364,7 +368,14 @@ __global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel
       if (!shareB) panel_store<TS, BKC>(Na + TILE_LDS, tid, rb);
     }
     __syncthreads();
+  };
+  int t = 0;
+  if (interior) {
+    const int nfast = (khi - klo) / BK - 1;     // iterations whose successor panel [kn, kn+BK) lies inside [klo, khi)
+    for (; t < nfast; ++t) iterate(t, std::true_type{});
+    // the generic loop below re-derives its addresses from (i0, j0, kn); fa/fb are not used again
   }
+  for (; t < ntk; ++t) iterate(t, std::false_type{});
 
   // epilogue: lane holds C[i = ..+r16][j = ..+g+4*reg]; 16 lanes -> 128 contiguous bytes of one column
   const bool to_slab = p.splitk > 1;

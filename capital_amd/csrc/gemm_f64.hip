@@ -173,10 +173,10 @@ __device__ __forceinline__ d2_t frag_read(const double* __restrict__ L, int row,
 // One k-step (4 deep) of the wave's SUB x SUB MFMA tiles.  `keep` has one bit per (a,b) sub-tile: sub-tiles that are
 // provably all-zero products (below the diagonal of a triangular output tile, or outside the band of a triangular
 // operand in the diagonal zone of a TRMM tile) are skipped at MFMA granularity (16 x 16) instead of tile granularity.
-template <int SUB, int COMP>
+template <int SUB, int COMP, bool ALL>
 __device__ __forceinline__ void mfma_step(d4_t (&acc)[SUB][SUB], const d2_t (&af)[SUB], const d2_t (&bf)[SUB], unsigned keep) {
   constexpr unsigned FULL = (1u << (SUB * SUB)) - 1u;
-  if (keep == FULL) {
+  if (ALL || keep == FULL) {
 #pragma unroll
     for (int a = 0; a < SUB; ++a)
 #pragma unroll
@@ -327,26 +327,30 @@ __global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel
       panel_load<TS, AK>(p.A, p.lda, i0, p.M, kn, khi, tid, p.a_vec, ra);
       if (!shareB) panel_load<TS, BKC>(p.B, p.ldb, j0, p.N, kn, khi, tid, p.b_vec, rb);
     }
-    // sub-tile activity of this wave for this panel (wave-uniform)
-    unsigned keep = out_keep;
-    const int kk = klo + t * BK;
-    // only panels that cross the diagonal band of this tile can have dead sub-tiles
-    const bool band = p.tri_side == CAPI_LEFT ? (kk < i0 + BM && kk + BK > i0) : (kk < j0 + BN && kk + BK > j0);
-    if (p.tri_side >= 0 && band && !p.no_skip) {
+    // sub-tile activity of this wave for this panel (wave-uniform).  FAST iterations are chosen so that every sub-tile
+    // is live and neither this panel nor the next crosses the diagonal band of a triangular operand.
+    unsigned keep = (1u << (SUB * SUB)) - 1u;
+    if (!FAST) {
+      keep = out_keep;
+      const int kk = klo + t * BK;
+      // only panels that cross the diagonal band of this tile can have dead sub-tiles
+      const bool band = p.tri_side == CAPI_LEFT ? (kk < i0 + BM && kk + BK > i0) : (kk < j0 + BN && kk + BK > j0);
+      if (p.tri_side >= 0 && band && !p.no_skip) {
 #pragma unroll
-      for (int a = 0; a < SUB; ++a)
+        for (int a = 0; a < SUB; ++a)
 #pragma unroll
-        for (int b = 0; b < SUB; ++b) {
-          bool on;
-          if (p.tri_side == CAPI_LEFT) {
-            const int rlo = i0 + wm * (TS / 2) + 16 * a;
-            on = p.tri_eff_upper ? (kk + BK - 1 >= rlo) : (kk <= rlo + 15);
-          } else {
-            const int clo = j0 + wn * (TS / 2) + 16 * b;
-            on = p.tri_eff_upper ? (kk <= clo + 15) : (kk + BK - 1 >= clo);
+          for (int b = 0; b < SUB; ++b) {
+            bool on;
+            if (p.tri_side == CAPI_LEFT) {
+              const int rlo = i0 + wm * (TS / 2) + 16 * a;
+              on = p.tri_eff_upper ? (kk + BK - 1 >= rlo) : (kk <= rlo + 15);
+            } else {
+              const int clo = j0 + wn * (TS / 2) + 16 * b;
+              on = p.tri_eff_upper ? (kk <= clo + 15) : (kk + BK - 1 >= clo);
+            }
+            if (!on) keep &= ~(1u << (a * SUB + b));
           }
-          if (!on) keep &= ~(1u << (a * SUB + b));
-        }
+      }
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -356,26 +360,42 @@ __global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel
 #pragma unroll
       for (int b = 0; b < SUB; ++b) bf[b] = frag_read<TS, BKC>(Lb, wn * (TS / 2) + b * 16 + r16, u, g);
       __builtin_amdgcn_s_setprio(1);      // keeps the cluster contiguous (+1 % measured)
-      mfma_step<SUB, 0>(acc, af, bf, keep);
-      mfma_step<SUB, 1>(acc, af, bf, keep);
+      mfma_step<SUB, 0, FAST>(acc, af, bf, keep);
+      mfma_step<SUB, 1, FAST>(acc, af, bf, keep);
       __builtin_amdgcn_s_setprio(0);
     }
     if (more) {
-      if (maskA && kn < i0 + BM && kn + BK > i0) panel_mask<TS, AK>(i0, kn, tid, keep_ge, p.tri_unit, ra);
-      if (maskB && kn < j0 + BN && kn + BK > j0) panel_mask<TS, BKC>(j0, kn, tid, keep_ge, p.tri_unit, rb);
+      if (!FAST) {
+        if (maskA && kn < i0 + BM && kn + BK > i0) panel_mask<TS, AK>(i0, kn, tid, keep_ge, p.tri_unit, ra);
+        if (maskB && kn < j0 + BN && kn + BK > j0) panel_mask<TS, BKC>(j0, kn, tid, keep_ge, p.tri_unit, rb);
+      }
       double* Na = lds + ((t + 1) & 1) * STAGE_LDS;
       panel_store<TS, AK>(Na, tid, ra);
       if (!shareB) panel_store<TS, BKC>(Na + TILE_LDS, tid, rb);
     }
     __syncthreads();
   };
-  int t = 0;
-  if (interior) {
-    const int nfast = (khi - klo) / BK - 1;     // iterations whose successor panel [kn, kn+BK) lies inside [klo, khi)
-    for (; t < nfast; ++t) iterate(t, std::true_type{});
-    // the generic loop below re-derives its addresses from (i0, j0, kn); fa/fb are not used again
+  // Iterations t in [0, nfast) have an interior successor panel.  Of those, FAST ones must also have every sub-tile live
+  // (not a diagonal tile of a triangular output) and keep clear of the band [tb0, tb1) of panels that cross the diagonal
+  // of a triangular operand -- both as the panel multiplied (t) and as the panel staged (t + 1).
+  const int nfast = (interior && !(p.out_uplo >= 0 && ti == tj)) ? (khi - klo) / BK - 1 : 0;
+  int tb0 = ntk, tb1 = ntk;                 // no band
+  if (p.tri_side >= 0) {
+    const int d0 = p.tri_side == CAPI_LEFT ? i0 : j0;
+    tb0 = d0 > klo ? (d0 - klo) / BK : 0;
+    tb1 = d0 + TS > klo ? (d0 + TS - klo + BK - 1) / BK : 0;
   }
-  for (; t < ntk; ++t) iterate(t, std::false_type{});
+  int t = 0;
+  while (t < ntk) {
+    const int fe = t + 1 < tb0 ? min(tb0 - 1, nfast) : (t >= tb1 ? nfast : t);
+    for (; t < fe; ++t) iterate(t, std::true_type{});
+    // fa/fb advance only in FAST iterations; the generic ones derive their addresses from (i0, j0, kn) -- resynchronise
+    const int ge = (t < tb1 && tb1 < nfast) ? tb1 : ntk;
+    const int t_in = t;
+    for (; t < ge; ++t) iterate(t, std::false_type{});
+    fa += (int64_t)(t - t_in) * ksa;
+    fb += (int64_t)(t - t_in) * ksb;
+  }
 
   // epilogue: lane holds C[i = ..+r16][j = ..+g+4*reg]; 16 lanes -> 128 contiguous bytes of one column
   const bool to_slab = p.splitk > 1;

@@ -11,7 +11,7 @@ import numpy as np
 import torch  # noqa: F401  (must precede loading the HIP library)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcapital_hip.so")
+LIB_PATH = os.environ.get("CAPITAL_HIP_LIB", os.path.join(_HERE, "libcapital_hip.so"))   # override: A/B builds of the same ABI
 
 NOTRANS, TRANS = 0, 1
 LEFT, RIGHT = 0, 1

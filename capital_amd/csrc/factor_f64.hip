@@ -3,7 +3,7 @@
 // Replaces LAPACKE_dpotrf / LAPACKE_dtrtri behind the reference's lapack::engine
 // (src/lapack/interface.hpp:30-58) and adds the block TRSM the reference lacks.
 //
-// Structure: one register-resident leaf kernel factors AND inverts a diagonal block of order <= 128 in a single
+// Structure: one LDS-resident MFMA leaf kernel factors AND inverts a diagonal block of order <= 128 in a single
 // launch (the reference's base case is exactly this pair: potrf, memcpy, trtri -- cholinv/policy.h:199-201,
 // cacqr.hpp:20-22); everything larger is the same recursion the reference runs across MPI ranks
 // (cholinv.hpp:87-165), executed here on one device with the MFMA tile kernel of gemm_f64.hip:
@@ -15,183 +15,6 @@ int capi_ws2_get(capi_handle_t h, size_t bytes, void** p);
 namespace {
 
 constexpr int LEAF = 128;
-
-// One workgroup factors AND inverts a diagonal block of order b <= 16*E entirely in registers.
-// Thread (tx,ty) = (tid&15, tid>>4) owns the E x E elements (row tx+16a, col ty+16c): a wave covers 16 contiguous
-// rows of 4 columns (128-byte global accesses) and the cyclic ownership keeps every thread busy as the active
-// window shrinks.  Each step publishes ONE row (and for the inverse one column) through a double-buffered LDS
-// line, so there is exactly one barrier per step and no read-modify-write traffic in LDS:
-//   potrf, step j : everybody reads the current row j, R[r,c] -= R[j,r]*R[j,c]/p_j for j<r<=c in registers; the owners
-//                   of row j scale it by 1/sqrt(p_j); the owners of row j+1 publish it (already updated).
-//   trtri, step p : owners of row p turn S[p,:] into X[p,:] = (e_p - S[p,:])/R[p,p] and publish it, owners of column p
-//                   publish R[:,p]; everybody does S[j,c] += R[j,p]*X[p,c] for j<p<=c.
-// A(upper) -> R in place with A = R^T R; X(upper) <- R^-1.  want_inv == 0 skips the inverse; zero_lower also writes
-// zeros below the diagonal of both outputs; invert_only: A already holds a triangular R (unit: unit diagonal).
-template <int E>
-__global__ __launch_bounds__(256, 1) void potrf_trtri_leaf_kernel(double* __restrict__ A, int64_t lda, double* __restrict__ X,
-                                                                  int64_t ldx, int b, int want_inv, int zero_lower,
-                                                                  int invert_only, int unit, int* __restrict__ info,
-                                                                  int info_base) {
-  constexpr int NB = 16 * E;
-  __shared__ double rowbuf[2][NB];
-  __shared__ double colbuf[2][NB];
-  __shared__ double invd[NB];
-  const int tid = threadIdx.x;
-  const int tx = tid & 15, ty = tid >> 4;
-  double r[E][E], s[E][E];
-
-#pragma unroll
-  for (int a = 0; a < E; ++a)
-#pragma unroll
-    for (int c = 0; c < E; ++c) {
-      const int row = tx + 16 * a, col = ty + 16 * c;
-      double v = 0.0;
-      if (row <= col && col < b) v = A[row + (int64_t)col * lda];
-      if (unit && row == col && col < b) v = 1.0;
-      r[a][c] = v;
-      s[a][c] = 0.0;
-    }
-
-  // reciprocal diagonal of R, filled by the Cholesky sweep (or directly when R is given)
-  if (invert_only) {
-#pragma unroll
-    for (int a = 0; a < E; ++a)
-#pragma unroll
-      for (int c = 0; c < E; ++c)
-        if (tx + 16 * a == ty + 16 * c && tx + 16 * a < b) invd[tx + 16 * a] = 1.0 / r[a][c];
-  }
-
-  if (!invert_only) {
-    if (tx == 0) {
-#pragma unroll
-      for (int c = 0; c < E; ++c) rowbuf[0][ty + 16 * c] = r[0][c];
-    }
-    __syncthreads();
-    for (int j = 0; j < b; ++j) {
-      const int cur = j & 1, jb = j >> 4, jt = j & 15;
-      double p = rowbuf[cur][j];
-      if (!(p > 0.0)) {
-        if (tid == 0) atomicCAS(info, 0, info_base + j + 1);
-        p = 1.0;
-      }
-      // 1/sqrt(p), sqrt(p), 1/p from v_rsq_f64 + Newton (a few ulp; the IEEE sqrt/div sequences cost ~10x more per step)
-      double y = __builtin_amdgcn_rsq(p);
-      y = y * (1.5 - 0.5 * p * y * y);
-      y = y * (1.5 - 0.5 * p * y * y);
-      double sq = p * y;
-      sq = sq + 0.5 * y * (p - sq * sq);
-      double ip = y * y;
-      ip = ip * (2.0 - p * ip);
-      if (tid == 0) invd[j] = y;
-      double rc[E], rr[E];
-#pragma unroll
-      for (int c = 0; c < E; ++c) rc[c] = rowbuf[cur][ty + 16 * c] * ip;
-#pragma unroll
-      for (int a = 0; a < E; ++a) rr[a] = rowbuf[cur][tx + 16 * a];
-#pragma unroll
-      for (int a = 0; a < E; ++a) {
-        if (16 * a + 15 <= j) continue;                 // every row of this block is finished (uniform)
-        const int row = tx + 16 * a;
-#pragma unroll
-        for (int c = a; c < E; ++c) {                   // blocks below the diagonal never change
-          const int col = ty + 16 * c;
-          if (row > j && row <= col) r[a][c] -= rr[a] * rc[c];
-        }
-      }
-      if (tx == jt) {                                   // owners of row j: scale it, set the pivot
-#pragma unroll
-        for (int a = 0; a < E; ++a)
-          if (a == jb) {
-#pragma unroll
-            for (int c = a; c < E; ++c) {
-              const int col = ty + 16 * c;
-              r[a][c] = col > j ? r[a][c] * y : (col == j ? sq : r[a][c]);
-            }
-          }
-      }
-      // owners of row j+1 publish it (its trailing part was just updated by themselves)
-      const int jn = j + 1;
-      if (jn < b && tx == (jn & 15)) {
-#pragma unroll
-        for (int a = 0; a < E; ++a)
-          if (a == (jn >> 4)) {
-#pragma unroll
-            for (int c = 0; c < E; ++c) rowbuf[cur ^ 1][ty + 16 * c] = r[a][c];
-          }
-      }
-      __syncthreads();
-    }
-  } else {
-    __syncthreads();
-  }
-
-  if (want_inv) {
-    for (int p = b - 1; p >= 0; --p) {
-      const int cur = p & 1, pb = p >> 4, pt = p & 15;
-      if (tx == pt) {                                   // owners of row p publish its partial sums
-#pragma unroll
-        for (int a = 0; a < E; ++a)
-          if (a == pb) {
-#pragma unroll
-            for (int c = 0; c < E; ++c) rowbuf[cur][ty + 16 * c] = s[a][c];
-          }
-      }
-      if (ty == pt) {                                   // owners of column p publish R[:,p]
-#pragma unroll
-        for (int c = 0; c < E; ++c)
-          if (c == pb) {
-#pragma unroll
-            for (int a = 0; a < E; ++a) colbuf[cur][tx + 16 * a] = r[a][c];
-          }
-      }
-      __syncthreads();
-      const double ipp = invd[p];
-      double xr[E], rcol[E];
-#pragma unroll
-      for (int c = 0; c < E; ++c) {
-        const int col = ty + 16 * c;
-        xr[c] = col >= p && col < b ? ((col == p ? 1.0 : 0.0) - rowbuf[cur][col]) * ipp : 0.0;   // X[p,col]
-      }
-#pragma unroll
-      for (int a = 0; a < E; ++a) rcol[a] = colbuf[cur][tx + 16 * a];
-#pragma unroll
-      for (int a = 0; a < E; ++a) {
-        if (16 * a >= p) continue;                      // no row of this block lies above row p (uniform)
-        const int row = tx + 16 * a;
-#pragma unroll
-        for (int c = a; c < E; ++c) {
-          if (16 * c + 15 < p) continue;                // X[p, these columns] = 0 (uniform)
-          if (row < p) s[a][c] += rcol[a] * xr[c];
-        }
-      }
-      if (tx == pt) {
-#pragma unroll
-        for (int a = 0; a < E; ++a)
-          if (a == pb) {
-#pragma unroll
-            for (int c = 0; c < E; ++c) s[a][c] = xr[c];
-          }
-      }
-      // buffers of parity `cur` are rewritten two steps from now; the next step's barrier separates the uses
-    }
-  }
-
-#pragma unroll
-  for (int a = 0; a < E; ++a)
-#pragma unroll
-    for (int c = 0; c < E; ++c) {
-      const int row = tx + 16 * a, col = ty + 16 * c;
-      if (row < b && col < b) {
-        if (row <= col) {
-          if (!invert_only) A[row + (int64_t)col * lda] = r[a][c];
-          if (want_inv) X[row + (int64_t)col * ldx] = s[a][c];
-        } else if (zero_lower) {
-          if (!invert_only) A[row + (int64_t)col * lda] = 0.0;
-          if (want_inv) X[row + (int64_t)col * ldx] = 0.0;
-        }
-      }
-    }
-}
 
 // ------------------------------------------------------------------------------------------------------------------
 // MFMA-blocked leaf: one workgroup factors AND inverts a diagonal block of order b <= 128 held in LDS (128 x 130 doubles,
@@ -448,13 +271,17 @@ int potrf_trtri_rec(capi_handle_t h, int64_t n, double* A, int64_t lda, double* 
   RC(capi_ws2_get(h, sizeof(double) * (size_t)n1 * (size_t)n2, &w));
   RC(capi_dtrmm_oop(h, CAPI_LEFT, CAPI_UPPER, CAPI_NOTRANS, CAPI_NONUNIT, n1, n2, 1.0, X, ldx, A12, lda, (double*)w, n1));
   RC(capi_dtrmm_oop(h, CAPI_RIGHT, CAPI_UPPER, CAPI_NOTRANS, CAPI_NONUNIT, n1, n2, -1.0, X22, ldx, (double*)w, n1, X12, ldx));
-  if (zero_lower) {
-    // lower-left n2 x n1 blocks of both outputs
-    hipStream_t s = h->stream;
-    CAPI_HIP_CHECK(h, hipMemset2DAsync(A + n1, sizeof(double) * lda, 0, sizeof(double) * n2, n1, s));
-    CAPI_HIP_CHECK(h, hipMemset2DAsync(X + n1, sizeof(double) * ldx, 0, sizeof(double) * n2, n1, s));
-  }
   return CAPI_OK;
+}
+
+// strictly-lower triangles of both outputs in one pass (nothing in the recursion reads or writes below the diagonal)
+__global__ void trizero2_kernel(int64_t n, double* __restrict__ A, int64_t lda, double* __restrict__ X, int64_t ldx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int64_t j = blockIdx.y; j < n && j < i; j += gridDim.y) {
+    A[i + j * lda] = 0.0;
+    X[i + j * ldx] = 0.0;
+  }
 }
 
 // in-place inverse of an upper triangular matrix (non-unit or unit diagonal)
@@ -554,8 +381,14 @@ int capi_dpotrf_trtri(capi_handle_t h, int64_t n, double* A, int64_t lda, double
   CAPI_REQUIRE(h, n >= 0 && n < (1LL << 31), "n");
   if (n == 0) return CAPI_OK;
   CAPI_REQUIRE(h, A && Rinv && lda >= n && ldi >= n, "operands");
+  if (n <= LEAF) return leaf_launch(h, A, lda, Rinv, ldi, (int)n, 1, 1, 0, 0, 0);
   { void* w; RC(capi_ws2_get(h, sizeof(double) * (size_t)(n / 2 + LEAF) * (size_t)(n / 2 + LEAF), &w)); }
-  return potrf_trtri_rec(h, n, A, lda, Rinv, ldi, 1, 0);
+  {
+    dim3 grid((unsigned)cdiv(n, 256), (unsigned)(n < 65535 ? n : 65535));
+    hipLaunchKernelGGL(trizero2_kernel, grid, dim3(256), 0, h->stream, n, A, lda, Rinv, ldi);
+    CAPI_HIP_CHECK(h, hipGetLastError());
+  }
+  return potrf_trtri_rec(h, n, A, lda, Rinv, ldi, 0, 0);
 }
 
 int capi_dpotrf(capi_handle_t h, int uplo, int64_t n, double* A, int64_t lda) {

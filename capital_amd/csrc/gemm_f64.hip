@@ -457,6 +457,128 @@ __global__ void scale_kernel(double* __restrict__ C, int64_t ldc, int M, int N, 
 
 typedef void (*gemm_kernel_t)(const GemmArgs);
 
+// ---- latency-bound sizes: 32 x 32 output tile, K in chunks of 256 loaded in ONE burst ---------------------------
+// The recursion's lower levels (orders 128 .. 1024) are chains of dependent products far too small to fill the chip; the
+// tile kernel above then runs a handful of workgroups through K/16 iterations of (load latency + barrier) each.  Here a
+// workgroup issues every load of a 256-deep chunk of both operand panels before anything else (32 x 16 bytes in flight
+// per thread), stages them through LDS in four 64-deep quarters as they land, and its four waves multiply one 16 x 16
+// MFMA tile each -- one exposed memory latency per 256 of K instead of one per 16, and 16x more workgroups per output.
+constexpr int ST = 32, SKC = 256, SQK = 64, SLD = ST + 2;
+
+template <bool KC>
+__device__ __forceinline__ void small_load(const double* __restrict__ X, int64_t ld, int r0, int R, int kc, int kend, int tid,
+                                           bool vec_ok, bool tri, bool keep_ge, bool unit, int quarter, d2_t (&v)[16]) {
+  // KC (k contiguous): row = tid>>3, k = kc + 2*(tid&7) + 16*q.   else (row contiguous): rows 2*(tid&15)+{0,1}, k = kc + (tid>>4) + 16*q
+#pragma unroll
+  for (int qq = 0; qq < 4; ++qq) {
+    const int q = 4 * quarter + qq;
+    int r[2], k[2];
+    if (KC) { r[0] = r[1] = r0 + (tid >> 3); k[0] = kc + 2 * (tid & 7) + 16 * q; k[1] = k[0] + 1; }
+    else { r[0] = r0 + 2 * (tid & 15); r[1] = r[0] + 1; k[0] = k[1] = kc + (tid >> 4) + 16 * q; }
+    const double* ptr = KC ? X + (int64_t)r[0] * ld + k[0] : X + (int64_t)k[0] * ld + r[0];
+    d2_t val = {0.0, 0.0};
+    if (r[1] < R && k[1] < kend && vec_ok) {
+      val = *(const d2_t*)ptr;
+    } else {
+      if (r[0] < R && k[0] < kend) val.x = ptr[0];
+      if (r[1] < R && k[1] < kend) val.y = ptr[1];
+    }
+    if (tri) {
+      if (keep_ge ? (k[0] < r[0]) : (k[0] > r[0])) val.x = 0.0;
+      if (keep_ge ? (k[1] < r[1]) : (k[1] > r[1])) val.y = 0.0;
+      if (unit) {
+        if (k[0] == r[0]) val.x = 1.0;
+        if (k[1] == r[1]) val.y = 1.0;
+      }
+    }
+    v[q] = val;
+  }
+}
+
+template <bool KC>
+__device__ __forceinline__ void small_store(double* __restrict__ L, int tid, int quarter, const d2_t (&v)[16]) {
+  // L[k][r], k relative to the chunk
+#pragma unroll
+  for (int qq = 0; qq < 4; ++qq) {
+    const int q = 4 * quarter + qq;
+    if (KC) {
+      const int k = 2 * (tid & 7) + 16 * q, r = tid >> 3;
+      L[k * SLD + r] = v[q].x;
+      L[(k + 1) * SLD + r] = v[q].y;
+    } else {
+      const int k = (tid >> 4) + 16 * q, r = 2 * (tid & 15);
+      *(d2_t*)&L[k * SLD + r] = v[q];
+    }
+  }
+}
+
+template <bool AK, bool BKC>
+__global__ __launch_bounds__(256, 1) void dgemm_small_kernel(const GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* La = lds;
+  double* Lb = lds + SKC * SLD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, g = lane >> 4, wm = wave & 1, wn = wave >> 1;
+  const int ti = blockIdx.x % p.tiles_m, tj = blockIdx.x / p.tiles_m;
+  const int i0 = ti * ST, j0 = tj * ST;
+  if (p.out_uplo == CAPI_UPPER && i0 > j0 + ST - 1) return;
+  if (p.out_uplo == CAPI_LOWER && j0 > i0 + ST - 1) return;
+  int klo = 0, khi = p.K;
+  if (p.tri_side == CAPI_LEFT) {
+    if (p.tri_eff_upper) klo = i0; else khi = min(p.K, i0 + ST);
+  } else if (p.tri_side == CAPI_RIGHT) {
+    if (p.tri_eff_upper) khi = min(p.K, j0 + ST); else klo = j0;
+  }
+  klo &= ~1;                                               // keep 16-byte alignment of k-contiguous loads
+  const bool keep_ge = (p.tri_side == CAPI_LEFT) == (p.tri_eff_upper != 0);
+  d4_t acc = {0.0, 0.0, 0.0, 0.0};
+  for (int kc = klo; kc < khi; kc += SKC) {
+    d2_t va[16], vb[16];
+#pragma unroll
+    for (int quarter = 0; quarter < 4; ++quarter) {        // issue order = consumption order (vmcnt counts in order)
+      small_load<AK>(p.A, p.lda, i0, p.M, kc, khi, tid, p.a_vec, p.tri_side == CAPI_LEFT, keep_ge, p.tri_unit, quarter, va);
+      small_load<BKC>(p.B, p.ldb, j0, p.N, kc, khi, tid, p.b_vec, p.tri_side == CAPI_RIGHT, keep_ge, p.tri_unit, quarter, vb);
+    }
+    if (kc > klo) __syncthreads();                         // the previous chunk's fragments have been consumed
+    const int nq = min(4, (khi - kc + SQK - 1) / SQK);
+#pragma unroll
+    for (int quarter = 0; quarter < 4; ++quarter) {
+      if (quarter >= nq) break;
+      small_store<AK>(La, tid, quarter, va);
+      small_store<BKC>(Lb, tid, quarter, vb);
+      __syncthreads();
+#pragma unroll
+      for (int s4 = 0; s4 < SQK / 4; ++s4) {
+        const int k = quarter * SQK + 4 * s4 + g;
+        const double a = La[k * SLD + wm * 16 + r16];
+        const double b = Lb[k * SLD + wn * 16 + r16];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a, acc, 0, 0, 0);
+      }
+    }
+  }
+  const int i = i0 + wm * 16 + r16;
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const int j = j0 + wn * 16 + g + 4 * reg;
+    bool ok = (i < p.M) && (j < p.N);
+    if (p.out_uplo == CAPI_UPPER) ok = ok && (i <= j);
+    if (p.out_uplo == CAPI_LOWER) ok = ok && (i >= j);
+    if (ok) {
+      double* c = p.C + i + (int64_t)j * p.ldc;
+      double r = p.alpha * acc[reg];
+      if (p.beta != 0.0) r += p.beta * (*c);
+      *c = r;
+    }
+  }
+}
+
+gemm_kernel_t pick_small(bool ak, bool bkc) {
+  return ak ? (bkc ? dgemm_small_kernel<true, true> : dgemm_small_kernel<true, false>)
+            : (bkc ? dgemm_small_kernel<false, true> : dgemm_small_kernel<false, false>);
+}
+
+
+
 template <int TS>
 gemm_kernel_t pick_kernel(bool ak, bool bkc) {
   return ak ? (bkc ? dgemm_tile_kernel<TS, true, true> : dgemm_tile_kernel<TS, true, false>)
@@ -515,6 +637,38 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
   }
   static const bool dbg = getenv("CAPI_DEBUG_GEMM") != nullptr;
   if (dbg) fprintf(stderr, "[capi gemm] M=%d N=%d K=%d uplo=%d tri=%d -> ts=%d splitk=%d est=%.1f us\n", p.M, p.N, p.K, p.out_uplo, p.tri_side, best_ts, best_s, best);
+  // latency-bound sizes go to the burst-load 32-tile kernel: one workgroup per CU (139 KB of LDS), per 256-deep chunk
+  // ~2 us of exposed load latency + 64 MFMAs per wave
+  {
+    static const char* force_small = getenv("CAPI_SMALL");
+    const double nt32 = (double)cdiv(p.M, ST) * (double)cdiv(p.N, ST) * (p.out_uplo >= 0 ? 0.5 : 1.0);
+    const double keff = tri ? 0.5 * p.K + 16.0 : (double)p.K;
+    const double chunks = keff / SKC < 1.0 ? 1.0 : keff / SKC;
+    const double t_small = (double)cdiv((int64_t)nt32, h->num_cu) * (chunks * 2.0 + keff * (16.0 / 2200.0) * 4.0 / 4.0) + 3.0;
+    bool use_small = p.M <= 512 && p.N <= 512 && p.K <= 2048;      // measured: 1.5-2x faster up to order 512, slower from 1024
+    if (force_small) use_small = atoi(force_small) != 0 && p.M <= 4096 && p.N <= 4096;
+    if (dbg) fprintf(stderr, "[capi gemm]   small-kernel estimate %.1f us -> %s\n", t_small, use_small ? "small" : "tile");
+    if (use_small) {
+      p.ts = ST;
+      p.tiles_m = (int)cdiv(p.M, ST);
+      p.tiles_n = (int)cdiv(p.N, ST);
+      p.ntiles = p.tiles_m * p.tiles_n;
+      p.a_vec = (((uintptr_t)p.A & 15) == 0) && ((p.lda & 1) == 0);
+      p.b_vec = (((uintptr_t)p.B & 15) == 0) && ((p.ldb & 1) == 0);
+      p.splitk = 1;
+      gemm_kernel_t k = pick_small(ak, bkc);
+      const size_t lds_bytes = sizeof(double) * 2 * SKC * SLD;
+      static bool attr_set[4] = {false, false, false, false};
+      const int vi = (ak ? 2 : 0) + (bkc ? 1 : 0);
+      if (!attr_set[vi]) {
+        CAPI_HIP_CHECK(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr_set[vi] = true;
+      }
+      hipLaunchKernelGGL(k, dim3((unsigned)p.ntiles), dim3(256), lds_bytes, s, p);
+      CAPI_HIP_CHECK(h, hipGetLastError());
+      return CAPI_OK;
+    }
+  }
   p.ts = best_ts;
   p.tiles_m = (int)cdiv(p.M, p.ts);
   p.tiles_n = (int)cdiv(p.N, p.ts);

@@ -194,25 +194,15 @@ __device__ __forceinline__ void mfma_step(d4_t (&acc)[SUB][SUB], const d2_t (&af
 
 __device__ __forceinline__ void tile_of(const GemmArgs& p, int t, int& ti, int& tj) {
   if (p.out_uplo < 0) {
-    // bands of GROUP_M tile-rows (all tile-columns) are dealt to XCDs in order.  A left-side TRMM's work per tile
-    // depends on its tile-ROW, so there the bands run along columns instead: every XCD then gets every row.
-    const bool by_cols = (p.tri_side == CAPI_LEFT);
-    const int nm = by_cols ? p.tiles_n : p.tiles_m, nn = by_cols ? p.tiles_m : p.tiles_n;
+    // bands of GROUP_M tile-rows (all tile-columns) are dealt to XCDs in order
+    const int nm = p.tiles_m, nn = p.tiles_n;
     const int in_group = GROUP_M * nn;
     const int group = t / in_group;
     const int first_m = group * GROUP_M;
     const int gsz = min(nm - first_m, GROUP_M);
     const int loc = t - group * in_group;
-    const int a = first_m + loc % gsz;
-    int b = loc / gsz;
-    // a TRMM tile's k-range grows or shrinks linearly along b: issue the long ones first (longest-processing-time
-    // order inside each XCD's share; every share holds all values of b, so the shares stay balanced)
-    if (p.tri_side >= 0) {
-      const bool grows = (p.tri_side == CAPI_LEFT) ? !p.tri_eff_upper : (p.tri_eff_upper != 0);
-      if (grows) b = nn - 1 - b;
-    }
-    ti = by_cols ? b : a;
-    tj = by_cols ? a : b;
+    ti = first_m + loc % gsz;
+    tj = loc / gsz;
   } else {
     // t enumerates pairs (lo <= hi): t = hi*(hi+1)/2 + lo
     int hi = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
@@ -221,6 +211,21 @@ __device__ __forceinline__ void tile_of(const GemmArgs& p, int t, int& ti, int& 
     const int lo = t - (int)((int64_t)hi * (hi + 1) / 2);
     if (p.out_uplo == CAPI_UPPER) { ti = lo; tj = hi; } else { ti = hi; tj = lo; }
   }
+}
+
+// TRMM: a tile's k-range grows linearly along the triangular dimension, so the tiles are ranked longest first and
+// rank r goes to workgroup r.  The dispatcher deals workgroups round-robin over the 8 XCDs: every XCD receives every
+// 8th entry of the sorted list -- equal shares of long and short tiles, each share still longest-first (LPT), and with
+// a multiple of 8 tiles across the free dimension an XCD keeps seeing the same columns of the dense operand in its L2.
+__device__ __forceinline__ void trmm_tile_of(const GemmArgs& p, int r, int& ti, int& tj) {
+  const bool left = p.tri_side == CAPI_LEFT;
+  const int nfree = left ? p.tiles_n : p.tiles_m, ntri = left ? p.tiles_m : p.tiles_n;
+  int b = r / nfree;                       // position along the triangular dimension, 0 = longest k-range
+  const int a = r - b * nfree;
+  const bool longest_last = left ? !p.tri_eff_upper : (p.tri_eff_upper != 0);
+  if (longest_last) b = ntri - 1 - b;
+  ti = left ? b : a;
+  tj = left ? a : b;
 }
 
 template <int TS, bool AK, bool BKC>
@@ -248,9 +253,10 @@ __global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel
   const int nblk = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, qq = nblk >> 3, rr = nblk & 7;
   const int pid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-  const int z = pid / p.ntiles;
+  int z = pid / p.ntiles;
   int ti, tj;
-  tile_of(p, pid - z * p.ntiles, ti, tj);
+  if (p.tri_side >= 0 && p.splitk == 1) { z = 0; trmm_tile_of(p, bid, ti, tj); }
+  else tile_of(p, pid - z * p.ntiles, ti, tj);
   const int i0 = ti * BM, j0 = tj * BN;
 
   // k-range of this tile

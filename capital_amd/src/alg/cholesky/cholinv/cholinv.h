@@ -54,6 +54,9 @@ public:
     // bookkeeping exposed for tests / benches
     int64_t num_base_cases = 0, num_levels = 0;
     bool zeroed = false;
+    // top-level overlap state: the input's right part is copied, and the finished left part packed, on the second stream
+    const double* input = nullptr;
+    DimensionType early_split = 0;
   };
 
   template <typename MatrixType, typename ArgType, typename CommType>
@@ -82,8 +85,6 @@ public:
       capital::dev_zero(Ri, ld * ld);
       args.zeroed = true;
     }
-    CAPITAL_CHECK(capi_dlacpy(capital::handle(), 1, ld, ld, A.data(), ld, R, ld));
-
     // base-case size rule, cholinv.hpp:15-18
     U bcDimLocal = (U)(CommInfo.c * CommInfo.d);
     U bcMult = args.bc_mult_dim;
@@ -96,6 +97,28 @@ public:
     args.bcDimension = (U)CommInfo.d * bcDimLocal;
     args.num_base_cases = args.num_levels = 0;
 
+    // Only the leading block is needed to start the left half's recursion (a chain of latency-bound kernels): the
+    // rest of the input follows on the second stream and is awaited just before the top level's R12 product.
+    const U h1 = localDimension >> args.split;
+    args.input = A.data();
+    args.early_split = 0;
+    const bool will_split = !(((localDimension * (U)CommInfo.d) <= args.bcDimension) || (h1 < args.split));   // cholinv.hpp:93
+    if (will_split && h1 > 0 && h1 < ld) {
+      capi_handle_t hh = capital::handle();
+      CAPITAL_CHECK(capi_dlacpy(hh, 1, h1, h1, A.data(), ld, R, ld));
+      CAPITAL_CHECK(capi_event_record(hh, EV_INPUT_HEAD));
+      CAPITAL_CHECK(capi_stream_select(hh, 1));
+      CAPITAL_CHECK(capi_event_wait(hh, EV_INPUT_HEAD));       // (also orders this call after the previous call's packing)
+      CAPITAL_CHECK(capi_dlacpy(hh, 0, h1, ld - h1, A.data() + (int64_t)h1 * ld, ld, R + (int64_t)h1 * ld, ld));
+      CAPITAL_CHECK(capi_dlacpy(hh, 1, ld - h1, ld - h1, A.data() + h1 + (int64_t)h1 * ld, ld, R + h1 + (int64_t)h1 * ld, ld));
+      CAPITAL_CHECK(capi_event_record(hh, EV_INPUT_REST));
+      CAPITAL_CHECK(capi_stream_select(hh, 0));
+      args.early_split = h1;
+    } else {
+      CAPITAL_CHECK(capi_dlacpy(capital::handle(), 1, ld, ld, A.data(), ld, R, ld));
+    }
+
+
     // the reference's simulate() (cholinv.hpp:50-83) pre-allocates every level's tables; here ONE arena covers the
     // deepest concurrent need: panels + partial sums of the top level, or the aggregated base case
     const bool single = (CommInfo.d == 1 && CommInfo.c == 1);
@@ -107,8 +130,16 @@ public:
     invoke(args, CommInfo, R, Ri, ld, (U)0, localDimension, globalDimension);
 
     if (packed) {
-      serialize<uppertri, uppertri>::invoke(args.Rfull, args.R, 0, ld, 0, ld, 0, ld, 0, ld);
-      serialize<uppertri, uppertri>::invoke(args.Rinvfull, args.Rinv, 0, ld, 0, ld, 0, ld, 0, ld);
+      const U e = args.early_split;     // columns [0,e) of both factors and rows [0,e) of R were packed during the right half
+      if (e > 0) {
+        pack_block(args, CAPI_UPPERTRI, R, (double*)args.R.data(), ld, e, ld, e, ld);                                     // R22
+        pack_block(args, CAPI_UPPERTRI, Ri, (double*)args.Rinv.data(), ld, e, ld, e, ld);                                 // Rinv22
+        if (args.complete_inv) pack_block(args, CAPI_RECT, Ri, (double*)args.Rinv.data(), ld, e, ld, 0, e);              // Rinv12
+        CAPITAL_CHECK(capi_event_wait(capital::handle(), EV_EARLY_PACK));
+      } else {
+        serialize<uppertri, uppertri>::invoke(args.Rfull, args.R, 0, ld, 0, ld, 0, ld, 0, ld);
+        serialize<uppertri, uppertri>::invoke(args.Rinvfull, args.Rinv, 0, ld, 0, ld, 0, ld, 0, ld);
+      }
     }
     if (!IP::keep_arena) { capital::sync(); args.work = matmult::arena(); }
     CRITTER_STOP(CI::factor);
@@ -125,6 +156,17 @@ public:
   }
 
 private:
+  // event slots of the top-level overlap (matmult::summa's pipe uses slots below 1000)
+  static constexpr int EV_INPUT_HEAD = 1020, EV_INPUT_REST = 1021, EV_TOP_R12 = 1022, EV_EARLY_PACK = 1023;
+
+  // columns [x0,x1), rows [y0,y1) of a full local image into the packed (uppertri) factor; shape = what is copied per column
+  template <typename ArgType>
+  static void pack_block(ArgType&, int shape, const double* full, double* packed_dst, int64_t ld, int64_t x0, int64_t x1, int64_t y0,
+                         int64_t y1) {
+    CAPITAL_CHECK(capi_serialize_shape(capital::handle(), shape, CAPI_RECT, CAPI_UPPERTRI, full, ld, ld, packed_dst, ld, ld,
+                                       x0, x1, y0, y1, x0, x1, y0, y1));
+  }
+
   template <typename M, typename CommType>
   static matrix<typename M::ScalarType, typename M::DimensionType, rect> construct(M& src, CommType&& CommInfo) {
     const auto ld = src.num_rows_local();
@@ -157,6 +199,8 @@ private:
 
     invoke(args, t, R, Ri, ld, start, split1, globalDim >> 1);                          // 1
 
+    const bool top = (localDim == args.localDimension) && args.early_split == split1;
+    if (top) CAPITAL_CHECK(capi_event_wait(h, EV_INPUT_REST));                          // the input's right part has landed
     CRITTER_START(CI::trsm);                                                            // 2
     {
       const int64_t mark = ws.top;
@@ -172,6 +216,17 @@ private:
       }
       CAPITAL_CHECK(capi_dlacpy(h, 0, split1, split2, W.p, W.ld, A12.p, ld));            // R12 into R (cholinv.hpp:122)
       CRITTER_STOP(CI::trsm);
+      if (top && !std::is_same<typename SP::structure, rect>::value) {
+        // R11, R12 and Rinv11 are final: pack them beside the trailing update and the right half (second stream)
+        CAPITAL_CHECK(capi_event_record(h, EV_TOP_R12));
+        CAPITAL_CHECK(capi_stream_select(h, 1));
+        CAPITAL_CHECK(capi_event_wait(h, EV_TOP_R12));
+        pack_block(args, CAPI_UPPERTRI, R, (double*)args.R.data(), ld, (U)0, split1, (U)0, split1);
+        pack_block(args, CAPI_RECT, R, (double*)args.R.data(), ld, split1, ld, (U)0, split1);
+        pack_block(args, CAPI_UPPERTRI, Ri, (double*)args.Rinv.data(), ld, (U)0, split1, (U)0, split1);
+        CAPITAL_CHECK(capi_event_record(h, EV_EARLY_PACK));
+        CAPITAL_CHECK(capi_stream_select(h, 0));
+      }
 
       CRITTER_START(CI::tmu);                                                           // 3
       if (single) {

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from capital_amd import capi
 h = capi.Handle(0)
-def timeit(fn, reps=50):
+def timeit(fn, reps=20):
     for _ in range(3): fn()
     h.sync()
     ms = C.c_float()
@@ -13,8 +13,9 @@ def timeit(fn, reps=50):
     h.call("capi_timer_stop_ms", C.byref(ms))
     return ms.value / reps * 1e3
 out = []
-for n in (128, 256, 512, 1024, 2048):
-    ld = 4096
+sizes = [int(x) for x in sys.argv[1:]] or [128, 256, 512, 1024, 2048]
+for n in sizes:
+    ld = max(4096, n)
     T = torch.rand((ld, ld), dtype=torch.float64, device="cuda")
     B = torch.rand((ld, ld), dtype=torch.float64, device="cuda")
     W = torch.zeros((ld, ld), dtype=torch.float64, device="cuda")

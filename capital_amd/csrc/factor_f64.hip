@@ -27,87 +27,253 @@ constexpr int LEAF = 128;
 //   W_k = R_kj * X_jj (k < j),  X_ij = -sum_{k=i..j-1} X_ik W_k  (products in registers, barrier, then written),  X_jj = V_j^T.
 // The 16-step diagonal phases are the critical path (~250 cycles a step); everything else is a few hundred MFMAs.
 typedef double d4l_t __attribute__((ext_vector_type(4)));
+typedef double d2l_t __attribute__((ext_vector_type(2)));
 constexpr int LB = 128, LLD = 130, LNT = 8;
 
-// GIVEN: the tile already holds a finished triangular factor U (inverse-only calls); only V = U^-T is formed.
-// Branch-free per-step body (selects instead of exec-mask branches) and a rolled loop: the fully unrolled, branchy form
-// spent ~150 instructions and several SGPR spills per step on what is a ~40-instruction dependency chain.
+__device__ __forceinline__ double readlane_f64(double x, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), l), hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+  return __hiloint2double(hi, lo);
+}
+
+// The 16 x 16 diagonal tile, factored AND inverted by ONE wave with the tile in MFMA accumulator layout (the other three
+// waves wait at the barrier that follows).  Four block steps of width 4 instead of sixteen scalar steps:
+//   T (symmetric, both triangles kept) and Z (starts as I, ends as V = U^-T) live as D-layout registers: lane (c = l&15,
+//   g = l>>4), register r  <->  element [g + 4r][c].  Rows kb..kb+3 are then register kb/4 -- which, read as an MFMA
+//   operand, is exactly the 16 x 4 panel T[:,kb..kb+3] (by symmetry) resp. Z^T's panel: no data movement at all.
+//   1. the 4 x 4 diagonal block travels by v_readlane; every lane factors it and inverts it (W = L4^-1), uniformly;
+//   2. panels   Lp = T[:,kb:kb+4] W^T,  Ep = E[:,kb:kb+4] W^T     one MFMA each  (A = W padded to 16 x 4, B = the register)
+//   3. updates  T -= Lp Lp^T,  Z -= Lp Ep^T                        one MFMA each
+//   4. rows kb..kb+3 of T and Z become Lp and Ep (U's rows, V's rows).
+// The dependency chain is 4 x (four pivots + two MFMA latencies) instead of 16 x (LDS round trip + barrier): ~3k cycles
+// per tile against ~9.5k.  GIVEN: the tile already holds a finished triangular factor U; only V is formed.
 template <bool GIVEN>
-__device__ __forceinline__ void leaf_diag(double* __restrict__ M, double* __restrict__ Vs, double (*rowU)[16], double (*rowW)[16],
-                                          int k, int tid, bool unit, int* __restrict__ info, int info_base, int b) {
-  const int i = tid & 15, j = tid >> 4, k0 = 16 * k;
-  double a = M[(k0 + i) + (k0 + j) * LLD];
-  if (i > j) a = 0.0;
-  if (GIVEN && unit && i == j) a = 1.0;
-  double w = 0.0;                       // accumulates sum_m U[m][i] V[m][j], becomes V[i][j] (j <= i)
-  if (i == 0) { rowU[0][j] = a; rowW[0][j] = 0.0; }
-  __syncthreads();
-#pragma nounroll
-  for (int s = 0; s < 16; ++s) {
-    const int cur = s & 1;
-    double p = rowU[cur][s];
-    const double ui = rowU[cur][i], uj = rowU[cur][j], wj = rowW[cur][j];
-    double y, sq;
+__device__ __forceinline__ void leaf_diag_mfma(double* __restrict__ M, double* __restrict__ Vs, int k, int lane, bool unit,
+                                               int* __restrict__ info, int info_base, int b) {
+  const int c = lane & 15, g = lane >> 4, k0 = 16 * k;
+  d4l_t T, Z;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = g + 4 * r;
+    const int lo = row < c ? row : c, hi = row < c ? c : row;
+    double t = M[(k0 + lo) + (k0 + hi) * LLD];           // upper triangle is authoritative: symmetrise on the way in
     if (GIVEN) {
-      p = p == 0.0 ? 1.0 : p;
-      y = 1.0 / p;                      // row s of U is final: y = 1/u_ss
-      sq = p;
-    } else {
-      if (!(p > 0.0)) {
-        if (tid == 0 && k0 + s < b) atomicCAS(info, 0, info_base + k0 + s + 1);
-        p = 1.0;
-      }
-      y = __builtin_amdgcn_rsq(p);
-      y = y * (1.5 - 0.5 * p * y * y);
-      y = y * (1.5 - 0.5 * p * y * y);
-      sq = p * y;
-      sq = sq + 0.5 * y * (p - sq * sq);
+      t = row <= c ? M[(k0 + row) + (k0 + c) * LLD] : 0.0;
+      if (unit && row == c) t = 1.0;
     }
-    const bool gt = i > s, eq = i == s;
-    const double vsj = j <= s ? ((j == s ? 1.0 : 0.0) - wj) * y : 0.0;               // V[s][j]
-    const double usi = GIVEN ? ui : ui * y;                                           // U[s][i]
-    if (!GIVEN) {
-      const double upd = a - ui * uj * (y * y);
-      const double fin = j > s ? uj * y : (j == s ? sq : 0.0);
-      a = eq ? fin : ((gt && i <= j) ? upd : a);
-    }
-    w = eq ? vsj : (gt ? w + usi * vsj : w);
-    if (i == s + 1) { rowU[cur ^ 1][j] = a; rowW[cur ^ 1][j] = w; }
-    __syncthreads();
+    T[r] = t;
+    Z[r] = row == c ? 1.0 : 0.0;
   }
-  M[(k0 + i) + (k0 + j) * LLD] = i <= j ? a : 0.0;
-  Vs[k * 256 + i + j * 16] = j <= i ? w : 0.0;          // V[i][j], stored [col][row]-major with ld 16
+#pragma unroll
+  for (int kb4 = 0; kb4 < 4; ++kb4) {
+    const int kb = 4 * kb4;
+    // 4 x 4 diagonal block, lower triangle d[a][bb] = T[kb+a][kb+bb]: lane 16a + kb + bb, register kb4
+    double d[4][4];
+#pragma unroll
+    for (int a_ = 0; a_ < 4; ++a_)
+#pragma unroll
+      for (int bb = 0; bb <= a_; ++bb)
+        d[a_][bb] = GIVEN ? readlane_f64(T[kb4], 16 * bb + kb + a_)      // L4[a][bb] = U[kb+bb][kb+a]
+                          : readlane_f64(T[kb4], 16 * a_ + kb + bb);
+    double l[4][4], y[4], w[4][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      double p = d[s][s];
+      if (!GIVEN) {
+#pragma unroll
+        for (int m = 0; m < s; ++m) p -= l[s][m] * l[s][m];
+        if (!(p > 0.0)) {
+          if (lane == 0 && k0 + kb + s < b) atomicCAS(info, 0, info_base + k0 + kb + s + 1);
+          p = 1.0;
+        }
+        // 1/sqrt(p) from v_rsq_f64 + Newton (a few ulp; the IEEE sqrt/div sequences cost ~10x more per step)
+        double ys = __builtin_amdgcn_rsq(p);
+        ys = ys * (1.5 - 0.5 * p * ys * ys);
+        ys = ys * (1.5 - 0.5 * p * ys * ys);
+        y[s] = ys;
+#pragma unroll
+        for (int a_ = s + 1; a_ < 4; ++a_) {
+          double x = d[a_][s];
+#pragma unroll
+          for (int m = 0; m < s; ++m) x -= l[a_][m] * l[s][m];
+          l[a_][s] = x * ys;
+        }
+      } else {
+        p = p == 0.0 ? 1.0 : p;
+        y[s] = 1.0 / p;                                  // row s of U is final: y = 1/u_ss
+#pragma unroll
+        for (int a_ = s + 1; a_ < 4; ++a_) l[a_][s] = d[a_][s];
+      }
+    }
+    // W = L4^-1 (lower), uniform
+#pragma unroll
+    for (int a_ = 0; a_ < 4; ++a_) {
+      w[a_][a_] = y[a_];
+#pragma unroll
+      for (int bb = 0; bb < a_; ++bb) {
+        double x = 0.0;
+#pragma unroll
+        for (int m = bb; m < a_; ++m) x += l[a_][m] * w[m][bb];
+        w[a_][bb] = -x * y[a_];
+      }
+    }
+    // A operand of the panel products: lane (i' = c, kk = g) supplies Wpad[i'][kk] (rows >= 4 and kk > i' are zero)
+    double wa = 0.0;
+#pragma unroll
+    for (int a_ = 0; a_ < 4; ++a_)
+#pragma unroll
+      for (int bb = 0; bb <= a_; ++bb)
+        if (c == a_ && g == bb) wa = w[a_][bb];
+    const d4l_t zero4 = {0.0, 0.0, 0.0, 0.0};
+    // panels: register 0 of W * (rows kb.. as B operand) is lane (i = c, g = column of the panel)
+    double Lp;
+    if (GIVEN) {
+      Lp = T[kb4];                                       // U[kb+g][c] = L[c][kb+g]
+    } else {
+      const d4l_t pr = __builtin_amdgcn_mfma_f64_16x16x4f64(wa, T[kb4], zero4, 0, 0, 0);
+      Lp = pr[0];
+    }
+    if (c < kb + g) Lp = 0.0;                            // L is lower triangular; rows above the block are finished
+    const d4l_t er = __builtin_amdgcn_mfma_f64_16x16x4f64(wa, Z[kb4], zero4, 0, 0, 0);
+    const double Ep = er[0];
+    if (!GIVEN) T = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lp, Lp, T, 0, 0, 0);
+    Z = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lp, Ep, Z, 0, 0, 0);
+    T[kb4] = Lp;
+    Z[kb4] = Ep;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = g + 4 * r;
+    M[(k0 + row) + (k0 + c) * LLD] = row <= c ? T[r] : 0.0;      // U, zeros below the diagonal
+    Vs[k * 256 + row + c * 16] = c <= row ? Z[r] : 0.0;          // V[row][c], stored [col][row]-major with ld 16
+  }
+}
+
+// upper triangle of the LDS tile to global (zeros below the diagonal on request): the LDS reads of a round are issued
+// together, then its stores (16-byte stores of row pairs when the block allows)
+__device__ __forceinline__ void leaf_store_upper(const double* __restrict__ M, double* __restrict__ G, int64_t ldg, int b,
+                                                 int zero_lower, int tid) {
+  if ((((uintptr_t)G & 15) == 0) && ((ldg & 1) == 0) && ((b & 1) == 0)) {
+    const int rp = 2 * (tid & 63), cq = tid >> 6;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      d2l_t v[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int col = cq + 4 * (16 * half + q);
+        d2l_t x = *(const d2l_t*)&M[rp + col * LLD];
+        if (rp > col) x.x = 0.0;
+        if (rp + 1 > col) x.y = 0.0;
+        v[q] = x;
+      }
+      if (rp < b) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int col = cq + 4 * (16 * half + q);
+          if (col < b) {
+            if (rp + 1 <= col || zero_lower) *(d2l_t*)&G[rp + (int64_t)col * ldg] = v[q];
+            else if (rp <= col) G[rp + (int64_t)col * ldg] = v[q].x;
+          }
+        }
+      }
+    }
+    return;
+  }
+  const int row = tid & 127, half = tid >> 7;
+  for (int base = 0; base < b; base += 32) {
+    double v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int col = base + half + 2 * q;
+      v[q] = (row <= col) ? M[row + col * LLD] : 0.0;
+    }
+    if (row < b) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int col = base + half + 2 * q;
+        if (col < b && (row <= col || zero_lower)) G[row + (int64_t)col * ldg] = v[q];
+      }
+    }
+  }
 }
 
 __global__ __launch_bounds__(256, 1) void potrf_trtri_leaf128_kernel(double* __restrict__ A, int64_t lda, double* __restrict__ X,
                                                                       int64_t ldx, int b, int want_inv, int zero_lower,
                                                                       int invert_only, int unit, int* __restrict__ info,
-                                                                      int info_base) {
+                                                                      int info_base, long long* __restrict__ dbg) {
   extern __shared__ __attribute__((aligned(16))) double lds_leaf[];
+  int dbg_n = 0;
+#define LEAF_MARK() do { if (dbg && threadIdx.x == 0) dbg[dbg_n++] = clock64(); } while (0)
+  LEAF_MARK();
   double* M = lds_leaf;                       // LB x LLD
   double* Vs = M + LB * LLD;                  // LNT tiles of 16 x 16
-  double(*rowU)[16] = (double(*)[16])(Vs + LNT * 256);
-  double(*rowW)[16] = rowU + 2;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // SGPR: wave-level loops stay scalar
   const int r16 = lane & 15, g = lane >> 4;
   const int nk = (b + 15) >> 4;               // active 16-wide panels
 
-  // load (upper triangle; identity padding beyond b keeps the padded problem SPD)
-  for (int col = tid >> 7; col < 16 * nk; col += 2) {
-    const int row = tid & 127;
-    if (row < 16 * nk) {
-      double v = 0.0;
-      if (row < b && col < b) { if (row <= col) v = A[row + (int64_t)col * lda]; }
-      else if (row == col) v = 1.0;
-      M[row + col * LLD] = v;
+  // load (upper triangle; identity padding beyond b keeps the padded problem SPD).  Every load of the tile is in flight
+  // before the first LDS store (a load -> store loop exposed one HBM latency per column): 32 x 16 bytes per thread when
+  // the block is 16-byte aligned, 4 rounds of 16 x 8 bytes otherwise.
+  const int nrc = 16 * nk;
+  if ((((uintptr_t)A & 15) == 0) && ((lda & 1) == 0) && ((b & 1) == 0)) {
+    const int rp = 2 * (tid & 63), cq = tid >> 6;
+    d2l_t v[32];
+    // unconditional loads from a clamped (always valid) address, selects afterwards: a load inside a branch makes the
+    // compiler wait for it at the join, one exposed latency per column
+#pragma unroll
+    for (int it = 0; it < 32; ++it) {
+      const int col = cq + 4 * it;
+      const bool in = rp < b && col < b && rp <= col;
+      v[it] = *(const d2l_t*)(in ? &A[rp + (int64_t)col * lda] : A);
+    }
+#pragma unroll
+    for (int it = 0; it < 32; ++it) {
+      const int col = cq + 4 * it;
+      d2l_t x = v[it];
+      if (rp < b && col < b) {
+        if (rp > col) x.x = 0.0;
+        if (rp + 1 > col) x.y = 0.0;
+      } else {
+        x = (d2l_t){rp == col ? 1.0 : 0.0, rp + 1 == col ? 1.0 : 0.0};
+      }
+      v[it] = x;
+    }
+    if (rp < nrc) {
+#pragma unroll
+      for (int it = 0; it < 32; ++it) {
+        const int col = cq + 4 * it;
+        if (col < nrc) *(d2l_t*)&M[rp + col * LLD] = v[it];
+      }
+    }
+  } else {
+    const int row = tid & 127, half = tid >> 7;
+    for (int base = 0; base < nrc; base += 32) {
+      double v[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int col = base + half + 2 * q;
+        double x = (row == col) ? 1.0 : 0.0;
+        if (row < b && col < b) x = (row <= col) ? A[row + (int64_t)col * lda] : 0.0;
+        v[q] = x;
+      }
+      if (row < nrc) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int col = base + half + 2 * q;
+          if (col < nrc) M[row + col * LLD] = v[q];
+        }
+      }
     }
   }
   __syncthreads();
+  LEAF_MARK();
 
   for (int k = 0; k < nk; ++k) {
-    if (invert_only) leaf_diag<true>(M, Vs, rowU, rowW, k, tid, unit != 0, info, info_base, b);
-    else leaf_diag<false>(M, Vs, rowU, rowW, k, tid, false, info, info_base, b);
+    if (wave == 0) {
+      if (invert_only) leaf_diag_mfma<true>(M, Vs, k, lane, unit != 0, info, info_base, b);
+      else leaf_diag_mfma<false>(M, Vs, k, lane, false, info, info_base, b);
+    }
     __syncthreads();
+    LEAF_MARK();
     if (invert_only || k + 1 >= nk) continue;
     const int k0 = 16 * k;
     // panel: R_kc = V_k * A_kc
@@ -125,40 +291,54 @@ __global__ __launch_bounds__(256, 1) void potrf_trtri_leaf128_kernel(double* __r
       for (int q = 0; q < 4; ++q) M[(k0 + g + 4 * q) + (c0 + r16) * LLD] = acc[q];
     }
     __syncthreads();
-    // trailing: A_rc -= R_kr^T R_kc, k < r <= c
-    const int nt = nk - 1 - k, ntiles = nt * (nt + 1) / 2;
-    for (int t = wave; t < ntiles; t += 4) {
-      int hi = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-      while (hi * (hi + 1) / 2 > t) --hi;
-      while ((hi + 1) * (hi + 2) / 2 <= t) ++hi;
-      const int lo = t - hi * (hi + 1) / 2;
-      const int r0 = 16 * (k + 1 + lo), c0 = 16 * (k + 1 + hi);
-      d4l_t acc;
+    LEAF_MARK();
+    // trailing: A_rc -= R_kr^T R_kc, k < r <= c.  Tiles (lo <= hi) are dealt to the waves round-robin; the operands of a
+    // wave's NEXT tile are read while the MFMAs of the current one run (a tile is only 4 MFMAs: unpipelined, the LDS
+    // latency and the accumulator round trip cost three times the arithmetic).
+    {
+      const int nt = nk - 1 - k, ntiles = nt * (nt + 1) / 2;
+      int lo = 0, hi = 0;
+      auto advance = [&](int steps) { for (int q = 0; q < steps; ++q) { if (++lo > hi) { ++hi; lo = 0; } } };
+      advance(wave);
+      struct frag { d4l_t acc; double av[4], bv[4]; };
+      auto load = [&](int lo_, int hi_) {
+        frag f;
+        const int r0 = 16 * (k + 1 + lo_), c0 = 16 * (k + 1 + hi_);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) acc[q] = M[(r0 + g + 4 * q) + (c0 + r16) * LLD];
+        for (int q = 0; q < 4; ++q) f.acc[q] = M[(r0 + g + 4 * q) + (c0 + r16) * LLD];
 #pragma unroll
-      for (int st = 0; st < 4; ++st) {
-        const int m = 4 * st + g;
-        const double av = -M[(k0 + m) + (r0 + r16) * LLD];            // -R_kr[m][i=r16]
-        const double bv = M[(k0 + m) + (c0 + r16) * LLD];             //  R_kc[m][j=r16]
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        for (int st = 0; st < 4; ++st) {
+          const int m = 4 * st + g;
+          f.av[st] = -M[(k0 + m) + (r0 + r16) * LLD];               // -R_kr[m][i=r16]
+          f.bv[st] = M[(k0 + m) + (c0 + r16) * LLD];                //  R_kc[m][j=r16]
+        }
+        return f;
+      };
+      int t = wave;
+      frag cur;
+      if (t < ntiles) cur = load(lo, hi);
+      while (t < ntiles) {
+        const int clo = lo, chi = hi;
+        advance(4);
+        const bool more = t + 4 < ntiles;
+        const frag nxt = load(more ? lo : clo, more ? hi : chi);     // (unconditional: a re-read of this tile when it is the last)
+        d4l_t acc = cur.acc;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.av[st], cur.bv[st], acc, 0, 0, 0);
+        const int r0 = 16 * (k + 1 + clo), c0 = 16 * (k + 1 + chi);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) M[(r0 + g + 4 * q) + (c0 + r16) * LLD] = acc[q];
+        cur = nxt;
+        t += 4;
       }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) M[(r0 + g + 4 * q) + (c0 + r16) * LLD] = acc[q];
     }
     __syncthreads();
+    LEAF_MARK();
   }
 
-  if (!invert_only) {
-    for (int col = tid >> 7; col < b; col += 2) {
-      const int row = tid & 127;
-      if (row < b) {
-        if (row <= col) A[row + (int64_t)col * lda] = M[row + col * LLD];
-        else if (zero_lower) A[row + (int64_t)col * lda] = 0.0;
-      }
-    }
-  }
+  if (!invert_only) leaf_store_upper(M, A, lda, b, zero_lower, tid);
 
+  LEAF_MARK();
   if (want_inv) {
     for (int j = 0; j < nk; ++j) {
       const int j0 = 16 * j;
@@ -184,15 +364,24 @@ __global__ __launch_bounds__(256, 1) void potrf_trtri_leaf128_kernel(double* __r
       for (int i = wave; i < j; i += 4, ++ni) {
         const int i0 = 16 * i;
         d4l_t acc = {0.0, 0.0, 0.0, 0.0};
-        for (int k = i; k < j; ++k) {
+        double av[4], bv[4];
+        auto fetch = [&](int k, double (&a_)[4], double (&b_)[4]) {
           const int k0 = 16 * k;
 #pragma unroll
           for (int st = 0; st < 4; ++st) {
             const int m = 4 * st + g;
-            const double av = -M[(i0 + r16) + (k0 + m) * LLD];        // -X_ik[i=r16][m]
-            const double bv = M[(k0 + m) + (j0 + r16) * LLD];         //  W_k[m][q=r16]
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            a_[st] = -M[(i0 + r16) + (k0 + m) * LLD];                 // -X_ik[i=r16][m]
+            b_[st] = M[(k0 + m) + (j0 + r16) * LLD];                  //  W_k[m][q=r16]
           }
+        };
+        fetch(i, av, bv);
+        for (int k = i; k < j; ++k) {                                 // next step's operands are read during this step's MFMAs
+          double an[4], bn[4];
+          fetch(k + 1 < j ? k + 1 : k, an, bn);
+#pragma unroll
+          for (int st = 0; st < 4; ++st) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[st], bv[st], acc, 0, 0, 0);
+#pragma unroll
+          for (int st = 0; st < 4; ++st) { av[st] = an[st]; bv[st] = bn[st]; }
         }
         if (ni == 0) out[0] = acc; else out[1] = acc;
       }
@@ -210,15 +399,12 @@ __global__ __launch_bounds__(256, 1) void potrf_trtri_leaf128_kernel(double* __r
         M[(j0 + i) + (j0 + q) * LLD] = i <= q ? Vs[j * 256 + q + i * 16] : 0.0;   // X[i][q] = V[q][i]
       }
       __syncthreads();
+      LEAF_MARK();
     }
-    for (int col = tid >> 7; col < b; col += 2) {
-      const int row = tid & 127;
-      if (row < b) {
-        if (row <= col) X[row + (int64_t)col * ldx] = M[row + col * LLD];
-        else if (zero_lower) X[row + (int64_t)col * ldx] = 0.0;
-      }
-    }
+    leaf_store_upper(M, X, ldx, b, zero_lower, tid);
   }
+  LEAF_MARK();
+#undef LEAF_MARK
 }
 
 __global__ void scale2d_kernel(double* __restrict__ B, int64_t ldb, int64_t m, int64_t n, double alpha) {
@@ -243,8 +429,20 @@ int leaf_launch(capi_handle_t h, double* A, int64_t lda, double* X, int64_t ldx,
       CAPI_HIP_CHECK(h, hipFuncSetAttribute((const void*)potrf_trtri_leaf128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
       attr_set = true;
     }
+    static const bool trace = getenv("CAPI_LEAF_TRACE") != nullptr;
+    long long* dbg = nullptr;
+    if (trace) CAPI_HIP_CHECK(h, hipMalloc((void**)&dbg, sizeof(long long) * 64));
     hipLaunchKernelGGL(potrf_trtri_leaf128_kernel, dim3(1), dim3(256), lds_bytes, h->stream, A, lda, X, ldx, b, want_inv, zero_lower,
-                       invert_only, unit, h->d_info, info_base);
+                       invert_only, unit, h->d_info, info_base, dbg);
+    if (trace) {   // diagnostics only: phase timestamps (shader clock) of this launch
+      long long t[64];
+      CAPI_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+      CAPI_HIP_CHECK(h, hipMemcpy(t, dbg, sizeof(t), hipMemcpyDeviceToHost));
+      CAPI_HIP_CHECK(h, hipFree(dbg));
+      fprintf(stderr, "[leaf b=%d]", b);
+      for (int i = 1; i < 34; ++i) fprintf(stderr, " %lld", t[i] - t[i - 1]);
+      fprintf(stderr, "  total %lld\n", t[33] - t[0]);
+    }
   }
   CAPI_HIP_CHECK(h, hipGetLastError());
   return CAPI_OK;

@@ -28,7 +28,13 @@ constexpr int LEAF = 128;
 // The 16-step diagonal phases are the critical path (~250 cycles a step); everything else is a few hundred MFMAs.
 typedef double d4l_t __attribute__((ext_vector_type(4)));
 typedef double d2l_t __attribute__((ext_vector_type(2)));
-constexpr int LB = 128, LLD = 130, LNT = 8;
+#ifndef LEAF_LLD
+#define LEAF_LLD 129
+#endif
+constexpr int LB = 128, LLD = LEAF_LLD, LNT = 8;
+// 8 waves (2 per SIMD): every phase but the diagonal tile is instruction-issue bound on one wave per SIMD (a 16 x 16 tile
+// is 4 MFMAs behind ~100 address/copy instructions), so a second wave per SIMD nearly doubles those phases' rate
+constexpr int LEAF_THREADS = 512, LNW = LEAF_THREADS / 64;
 
 __device__ __forceinline__ double readlane_f64(double x, int l) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(x), l), hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
@@ -155,12 +161,12 @@ __device__ __forceinline__ void leaf_store_upper(const double* __restrict__ M, d
   if ((((uintptr_t)G & 15) == 0) && ((ldg & 1) == 0) && ((b & 1) == 0)) {
     const int rp = 2 * (tid & 63), cq = tid >> 6;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < 128 / (16 * LNW); ++half) {
       d2l_t v[16];
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const int col = cq + 4 * (16 * half + q);
-        d2l_t x = *(const d2l_t*)&M[rp + col * LLD];
+        const int col = cq + LNW * (16 * half + q);
+        d2l_t x = {M[rp + col * LLD], M[rp + 1 + col * LLD]};
         if (rp > col) x.x = 0.0;
         if (rp + 1 > col) x.y = 0.0;
         v[q] = x;
@@ -168,7 +174,7 @@ __device__ __forceinline__ void leaf_store_upper(const double* __restrict__ M, d
       if (rp < b) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-          const int col = cq + 4 * (16 * half + q);
+          const int col = cq + LNW * (16 * half + q);
           if (col < b) {
             if (rp + 1 <= col || zero_lower) *(d2l_t*)&G[rp + (int64_t)col * ldg] = v[q];
             else if (rp <= col) G[rp + (int64_t)col * ldg] = v[q].x;
@@ -178,25 +184,26 @@ __device__ __forceinline__ void leaf_store_upper(const double* __restrict__ M, d
     }
     return;
   }
+  constexpr int NH = LEAF_THREADS / 128;
   const int row = tid & 127, half = tid >> 7;
-  for (int base = 0; base < b; base += 32) {
+  for (int base = 0; base < b; base += 16 * NH) {
     double v[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      const int col = base + half + 2 * q;
-      v[q] = (row <= col) ? M[row + col * LLD] : 0.0;
+      const int col = base + half + NH * q;
+      v[q] = (row <= col && col < LB) ? M[row + col * LLD] : 0.0;
     }
     if (row < b) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const int col = base + half + 2 * q;
+        const int col = base + half + NH * q;
         if (col < b && (row <= col || zero_lower)) G[row + (int64_t)col * ldg] = v[q];
       }
     }
   }
 }
 
-__global__ __launch_bounds__(256, 1) void potrf_trtri_leaf128_kernel(double* __restrict__ A, int64_t lda, double* __restrict__ X,
+__global__ __launch_bounds__(LEAF_THREADS, 1) void potrf_trtri_leaf128_kernel(double* __restrict__ A, int64_t lda, double* __restrict__ X,
                                                                       int64_t ldx, int b, int want_inv, int zero_lower,
                                                                       int invert_only, int unit, int* __restrict__ info,
                                                                       int info_base, long long* __restrict__ dbg) {
@@ -209,6 +216,12 @@ __global__ __launch_bounds__(256, 1) void potrf_trtri_leaf128_kernel(double* __r
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // SGPR: wave-level loops stay scalar
   const int r16 = lane & 15, g = lane >> 4;
   const int nk = (b + 15) >> 4;               // active 16-wide panels
+  int tri_tab;                                // lane t: (lo, hi) of pair t in the enumeration t = hi (hi + 1) / 2 + lo
+  {
+    int hi_ = 0;
+    while ((hi_ + 1) * (hi_ + 2) / 2 <= lane) ++hi_;
+    tri_tab = (lane - hi_ * (hi_ + 1) / 2) | (hi_ << 4);
+  }
 
   // load (upper triangle; identity padding beyond b keeps the padded problem SPD).  Every load of the tile is in flight
   // before the first LDS store (a load -> store loop exposed one HBM latency per column): 32 x 16 bytes per thread when
@@ -216,18 +229,19 @@ __global__ __launch_bounds__(256, 1) void potrf_trtri_leaf128_kernel(double* __r
   const int nrc = 16 * nk;
   if ((((uintptr_t)A & 15) == 0) && ((lda & 1) == 0) && ((b & 1) == 0)) {
     const int rp = 2 * (tid & 63), cq = tid >> 6;
-    d2l_t v[32];
+    constexpr int NIT = 128 / LNW;
+    d2l_t v[NIT];
     // unconditional loads from a clamped (always valid) address, selects afterwards: a load inside a branch makes the
     // compiler wait for it at the join, one exposed latency per column
 #pragma unroll
-    for (int it = 0; it < 32; ++it) {
-      const int col = cq + 4 * it;
+    for (int it = 0; it < NIT; ++it) {
+      const int col = cq + LNW * it;
       const bool in = rp < b && col < b && rp <= col;
       v[it] = *(const d2l_t*)(in ? &A[rp + (int64_t)col * lda] : A);
     }
 #pragma unroll
-    for (int it = 0; it < 32; ++it) {
-      const int col = cq + 4 * it;
+    for (int it = 0; it < NIT; ++it) {
+      const int col = cq + LNW * it;
       d2l_t x = v[it];
       if (rp < b && col < b) {
         if (rp > col) x.x = 0.0;
@@ -239,18 +253,19 @@ __global__ __launch_bounds__(256, 1) void potrf_trtri_leaf128_kernel(double* __r
     }
     if (rp < nrc) {
 #pragma unroll
-      for (int it = 0; it < 32; ++it) {
-        const int col = cq + 4 * it;
-        if (col < nrc) *(d2l_t*)&M[rp + col * LLD] = v[it];
+      for (int it = 0; it < NIT; ++it) {
+        const int col = cq + LNW * it;
+        if (col < nrc) { M[rp + col * LLD] = v[it].x; M[rp + 1 + col * LLD] = v[it].y; }   // (odd LLD: 8-byte LDS accesses)
       }
     }
   } else {
+    constexpr int NH = LEAF_THREADS / 128;
     const int row = tid & 127, half = tid >> 7;
-    for (int base = 0; base < nrc; base += 32) {
+    for (int base = 0; base < nrc; base += 16 * NH) {
       double v[16];
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const int col = base + half + 2 * q;
+        const int col = base + half + NH * q;
         double x = (row == col) ? 1.0 : 0.0;
         if (row < b && col < b) x = (row <= col) ? A[row + (int64_t)col * lda] : 0.0;
         v[q] = x;
@@ -258,7 +273,7 @@ __global__ __launch_bounds__(256, 1) void potrf_trtri_leaf128_kernel(double* __r
       if (row < nrc) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-          const int col = base + half + 2 * q;
+          const int col = base + half + NH * q;
           if (col < nrc) M[row + col * LLD] = v[q];
         }
       }
@@ -277,7 +292,7 @@ __global__ __launch_bounds__(256, 1) void potrf_trtri_leaf128_kernel(double* __r
     if (invert_only || k + 1 >= nk) continue;
     const int k0 = 16 * k;
     // panel: R_kc = V_k * A_kc
-    for (int c = k + 1 + wave; c < nk; c += 4) {
+    for (int c = k + 1 + wave; c < nk; c += LNW) {
       const int c0 = 16 * c;
       d4l_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -297,9 +312,11 @@ __global__ __launch_bounds__(256, 1) void potrf_trtri_leaf128_kernel(double* __r
     // latency and the accumulator round trip cost three times the arithmetic).
     {
       const int nt = nk - 1 - k, ntiles = nt * (nt + 1) / 2;
-      int lo = 0, hi = 0;
-      auto advance = [&](int steps) { for (int q = 0; q < steps; ++q) { if (++lo > hi) { ++hi; lo = 0; } } };
-      advance(wave);
+      // (lo, hi) of tile t from a per-lane table (lane t holds pair t of the triangular enumeration): one v_readlane
+      // instead of ~70 scalar instructions of index stepping per tile -- these loops are instruction-issue bound
+      int lo, hi;
+      auto coords = [&](int t_) { const int e = __builtin_amdgcn_readlane(tri_tab, t_ < 63 ? t_ : 63); lo = e & 15; hi = e >> 4; };
+      coords(wave);
       struct frag { d4l_t acc; double av[4], bv[4]; };
       auto load = [&](int lo_, int hi_) {
         frag f;
@@ -319,17 +336,22 @@ __global__ __launch_bounds__(256, 1) void potrf_trtri_leaf128_kernel(double* __r
       if (t < ntiles) cur = load(lo, hi);
       while (t < ntiles) {
         const int clo = lo, chi = hi;
-        advance(4);
-        const bool more = t + 4 < ntiles;
+        const bool more = t + LNW < ntiles;
+        if (more) coords(t + LNW);
         const frag nxt = load(more ? lo : clo, more ? hi : chi);     // (unconditional: a re-read of this tile when it is the last)
-        d4l_t acc = cur.acc;
-#pragma unroll
-        for (int st = 0; st < 4; ++st) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.av[st], cur.bv[st], acc, 0, 0, 0);
+        // two independent accumulator chains (k-steps 0,1 and 2,3): a 4-deep chain of dependent MFMAs waits out the full
+        // pipeline latency three times
+        d4l_t acc = cur.acc, acc2 = {0.0, 0.0, 0.0, 0.0};
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.av[0], cur.bv[0], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.av[2], cur.bv[2], acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.av[1], cur.bv[1], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.av[3], cur.bv[3], acc2, 0, 0, 0);
+        acc += acc2;
         const int r0 = 16 * (k + 1 + clo), c0 = 16 * (k + 1 + chi);
 #pragma unroll
         for (int q = 0; q < 4; ++q) M[(r0 + g + 4 * q) + (c0 + r16) * LLD] = acc[q];
         cur = nxt;
-        t += 4;
+        t += LNW;
       }
     }
     __syncthreads();
@@ -340,66 +362,78 @@ __global__ __launch_bounds__(256, 1) void potrf_trtri_leaf128_kernel(double* __r
 
   LEAF_MARK();
   if (want_inv) {
-    for (int j = 0; j < nk; ++j) {
-      const int j0 = 16 * j;
-      // phase A: W_k = R_kj * X_jj for k < j (in place over tile (k,j)); X_jj[m][q] = V_j[q][m]
-      for (int k = wave; k < j; k += 4) {
-        const int k0 = 16 * k;
-        d4l_t acc = {0.0, 0.0, 0.0, 0.0};
+    // X = R^-1 in place over the factor (which has already gone to HBM), by halving: with X11 and X22 known,
+    // X12 = -(X11 R12) X22.  Levels h = 16, 32, 64 (tiles per block s = 1, 2, 4); every off-diagonal block of a level is
+    // independent of the others and each of its two products is a set of s*s independent 16 x 16 tiles -- 6 wide phases
+    // instead of the 8 x 3 narrow ones of a column-by-column substitution.  Both products overwrite their left operand's
+    // block, so a wave keeps its (at most two) tiles in registers until a barrier has seen every read.
+    __syncthreads();                                               // the factor's store above has read every tile
+    {
+      const int i = tid & 15, q = (tid >> 4) & 15, j = tid >> 8;     // diagonal tiles X_jj = V_j^T, 2 tiles per pass
+      for (int jj = j; jj < nk; jj += LEAF_THREADS / 256) M[(16 * jj + i) + (16 * jj + q) * LLD] = i <= q ? Vs[jj * 256 + q + i * 16] : 0.0;
+    }
+    __syncthreads();
+    LEAF_MARK();
+    for (int ls = 0; (1 << ls) < nk; ++ls) {
+      const int s_ = 1 << ls, per = s_ * s_, npairs = (nk + 2 * s_ - 1) >> (ls + 1), ntl = npairs * per;
+      // tile t of this level: pair p, row a and column c inside the pair's off-diagonal block.  A wave's second tile
+      // (only the last level has 16 tiles for 8 waves) is taken from the far end of the list: rows and columns mirror,
+      // so every wave gets the same number of k-steps in both phases (s + 1 of them instead of up to 2 s).
+      auto coords = [&](int t, int& ti, int& tj, int& c0) {
+        const int te = t < LNW ? t : ntl - 1 - (t - LNW);
+        const int p_ = te >> (2 * ls), w_ = te & (per - 1);
+        const int r0 = p_ << (ls + 1);
+        c0 = r0 + s_;
+        ti = r0 + (w_ & (s_ - 1));
+        tj = c0 + (w_ >> ls);
+      };
 #pragma unroll
-        for (int st = 0; st < 4; ++st) {
-          const int m = 4 * st + g;
-          const double av = M[(k0 + r16) + (j0 + m) * LLD];           // R_kj[i=r16][m]
-          const double bv = Vs[j * 256 + r16 + m * 16];               // X_jj[m][q=r16] = V_j[q][m]
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-        }
-        // all four fragment loads of this tile were consumed by the MFMAs above before the stores below (same wave)
+      for (int phase = 0; phase < 2; ++phase) {
+        d4l_t out[2];
+        int nt_ = 0;
+        for (int t = wave; t < ntl; t += LNW, ++nt_) {
+          int ti, tj, c0;
+          coords(t, ti, tj, c0);
+          d4l_t acc = {0.0, 0.0, 0.0, 0.0};
+          if (tj < nk) {
+            // phase 0: T_ij = sum_{k=ti}^{c0-1} X_ik R_kj        phase 1: X_ij = -sum_{k=c0}^{tj} T_ik X_kj
+            const int kb = phase == 0 ? ti : c0, ke = phase == 0 ? c0 : tj + 1;
+            const double* pa = M + (16 * ti + r16) + g * LLD;              // A operand: rows of tile-row ti, k along columns
+            const double* pb = M + g + (16 * tj + r16) * LLD;              // B operand: columns of tile-column tj, k along rows
+            double av[4], bv[4];
+            auto fetch = [&](int k, double (&a_)[4], double (&b_)[4]) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) M[(k0 + g + 4 * q) + (j0 + r16) * LLD] = acc[q];
-      }
-      __syncthreads();
-      // phase B: X_ij = -sum_{k=i}^{j-1} X_ik W_k for i < j; each wave keeps its (at most two) tiles in registers
-      d4l_t out[2];
-      int ni = 0;
-      for (int i = wave; i < j; i += 4, ++ni) {
-        const int i0 = 16 * i;
-        d4l_t acc = {0.0, 0.0, 0.0, 0.0};
-        double av[4], bv[4];
-        auto fetch = [&](int k, double (&a_)[4], double (&b_)[4]) {
-          const int k0 = 16 * k;
+              for (int st = 0; st < 4; ++st) {
+                a_[st] = pa[(16 * k + 4 * st) * LLD];
+                b_[st] = pb[16 * k + 4 * st];
+              }
+            };
+            fetch(kb, av, bv);
+            for (int k = kb; k < ke; ++k) {                          // the next step's operands are read during this step's MFMAs
+              double an[4], bn[4];
+              fetch(k + 1 < ke ? k + 1 : k, an, bn);
 #pragma unroll
-          for (int st = 0; st < 4; ++st) {
-            const int m = 4 * st + g;
-            a_[st] = -M[(i0 + r16) + (k0 + m) * LLD];                 // -X_ik[i=r16][m]
-            b_[st] = M[(k0 + m) + (j0 + r16) * LLD];                  //  W_k[m][q=r16]
+              for (int st = 0; st < 4; ++st) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[st], bv[st], acc, 0, 0, 0);
+#pragma unroll
+              for (int st = 0; st < 4; ++st) { av[st] = an[st]; bv[st] = bn[st]; }
+            }
           }
-        };
-        fetch(i, av, bv);
-        for (int k = i; k < j; ++k) {                                 // next step's operands are read during this step's MFMAs
-          double an[4], bn[4];
-          fetch(k + 1 < j ? k + 1 : k, an, bn);
-#pragma unroll
-          for (int st = 0; st < 4; ++st) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[st], bv[st], acc, 0, 0, 0);
-#pragma unroll
-          for (int st = 0; st < 4; ++st) { av[st] = an[st]; bv[st] = bn[st]; }
+          if (nt_ == 0) out[0] = acc; else out[1] = acc;
         }
-        if (ni == 0) out[0] = acc; else out[1] = acc;
-      }
-      __syncthreads();
-      ni = 0;
-      for (int i = wave; i < j; i += 4, ++ni) {
-        const int i0 = 16 * i;
-        const d4l_t acc = ni == 0 ? out[0] : out[1];
+        __syncthreads();
+        nt_ = 0;
+        for (int t = wave; t < ntl; t += LNW, ++nt_) {
+          int ti, tj, c0;
+          coords(t, ti, tj, c0);
+          const d4l_t acc = nt_ == 0 ? out[0] : out[1];
+          if (tj < nk) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) M[(i0 + g + 4 * q) + (j0 + r16) * LLD] = acc[q];
+            for (int qq = 0; qq < 4; ++qq) M[(16 * ti + g + 4 * qq) + (16 * tj + r16) * LLD] = phase == 0 ? acc[qq] : -acc[qq];
+          }
+        }
+        __syncthreads();
+        LEAF_MARK();
       }
-      // X_jj = V_j^T into the diagonal tile
-      {
-        const int i = tid & 15, q = tid >> 4;
-        M[(j0 + i) + (j0 + q) * LLD] = i <= q ? Vs[j * 256 + q + i * 16] : 0.0;   // X[i][q] = V[q][i]
-      }
-      __syncthreads();
-      LEAF_MARK();
     }
     leaf_store_upper(M, X, ldx, b, zero_lower, tid);
   }
@@ -432,7 +466,7 @@ int leaf_launch(capi_handle_t h, double* A, int64_t lda, double* X, int64_t ldx,
     static const bool trace = getenv("CAPI_LEAF_TRACE") != nullptr;
     long long* dbg = nullptr;
     if (trace) CAPI_HIP_CHECK(h, hipMalloc((void**)&dbg, sizeof(long long) * 64));
-    hipLaunchKernelGGL(potrf_trtri_leaf128_kernel, dim3(1), dim3(256), lds_bytes, h->stream, A, lda, X, ldx, b, want_inv, zero_lower,
+    hipLaunchKernelGGL(potrf_trtri_leaf128_kernel, dim3(1), dim3(LEAF_THREADS), lds_bytes, h->stream, A, lda, X, ldx, b, want_inv, zero_lower,
                        invert_only, unit, h->d_info, info_base, dbg);
     if (trace) {   // diagnostics only: phase timestamps (shader clock) of this launch
       long long t[64];
@@ -440,8 +474,9 @@ int leaf_launch(capi_handle_t h, double* A, int64_t lda, double* X, int64_t ldx,
       CAPI_HIP_CHECK(h, hipMemcpy(t, dbg, sizeof(t), hipMemcpyDeviceToHost));
       CAPI_HIP_CHECK(h, hipFree(dbg));
       fprintf(stderr, "[leaf b=%d]", b);
-      for (int i = 1; i < 34; ++i) fprintf(stderr, " %lld", t[i] - t[i - 1]);
-      fprintf(stderr, "  total %lld\n", t[33] - t[0]);
+      for (int i = 1; i < 33; ++i) fprintf(stderr, " %lld", t[i] - t[i - 1]);
+      fprintf(stderr, "  total %lld\n", t[32] - t[0]);
+
     }
   }
   CAPI_HIP_CHECK(h, hipGetLastError());

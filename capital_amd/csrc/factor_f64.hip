@@ -282,80 +282,85 @@ __global__ __launch_bounds__(LEAF_THREADS, 1) void potrf_trtri_leaf128_kernel(do
   __syncthreads();
   LEAF_MARK();
 
-  for (int k = 0; k < nk; ++k) {
-    if (wave == 0) {
-      if (invert_only) leaf_diag_mfma<true>(M, Vs, k, lane, unit != 0, info, info_base, b);
-      else leaf_diag_mfma<false>(M, Vs, k, lane, false, info, info_base, b);
-    }
+  if (invert_only) {
+    // the diagonal tiles of a given factor are independent: one per wave
+    for (int k = wave; k < nk; k += LNW) leaf_diag_mfma<true>(M, Vs, k, lane, unit != 0, info, info_base, b);
     __syncthreads();
     LEAF_MARK();
-    if (invert_only || k + 1 >= nk) continue;
-    const int k0 = 16 * k;
-    // panel: R_kc = V_k * A_kc
-    for (int c = k + 1 + wave; c < nk; c += LNW) {
-      const int c0 = 16 * c;
-      d4l_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int st = 0; st < 4; ++st) {
-        const int m = 4 * st + g;
-        const double av = Vs[k * 256 + r16 + m * 16];                 // V[i=r16][m]
-        const double bv = M[(k0 + m) + (c0 + r16) * LLD];             // A_kc[m][j=r16]
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) M[(k0 + g + 4 * q) + (c0 + r16) * LLD] = acc[q];
-    }
+  } else {
+    if (wave == 0) leaf_diag_mfma<false>(M, Vs, 0, lane, false, info, info_base, b);
     __syncthreads();
     LEAF_MARK();
-    // trailing: A_rc -= R_kr^T R_kc, k < r <= c.  Tiles (lo <= hi) are dealt to the waves round-robin; the operands of a
-    // wave's NEXT tile are read while the MFMAs of the current one run (a tile is only 4 MFMAs: unpipelined, the LDS
-    // latency and the accumulator round trip cost three times the arithmetic).
-    {
-      const int nt = nk - 1 - k, ntiles = nt * (nt + 1) / 2;
-      // (lo, hi) of tile t from a per-lane table (lane t holds pair t of the triangular enumeration): one v_readlane
-      // instead of ~70 scalar instructions of index stepping per tile -- these loops are instruction-issue bound
-      int lo, hi;
-      auto coords = [&](int t_) { const int e = __builtin_amdgcn_readlane(tri_tab, t_ < 63 ? t_ : 63); lo = e & 15; hi = e >> 4; };
-      coords(wave);
-      struct frag { d4l_t acc; double av[4], bv[4]; };
-      auto load = [&](int lo_, int hi_) {
-        frag f;
-        const int r0 = 16 * (k + 1 + lo_), c0 = 16 * (k + 1 + hi_);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) f.acc[q] = M[(r0 + g + 4 * q) + (c0 + r16) * LLD];
+    for (int k = 0; k + 1 < nk; ++k) {
+      const int k0 = 16 * k;
+      // panel: R_kc = V_k * A_kc
+      for (int c = k + 1 + wave; c < nk; c += LNW) {
+        const int c0 = 16 * c;
+        d4l_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
           const int m = 4 * st + g;
-          f.av[st] = -M[(k0 + m) + (r0 + r16) * LLD];               // -R_kr[m][i=r16]
-          f.bv[st] = M[(k0 + m) + (c0 + r16) * LLD];                //  R_kc[m][j=r16]
+          const double av = Vs[k * 256 + r16 + m * 16];                 // V[i=r16][m]
+          const double bv = M[(k0 + m) + (c0 + r16) * LLD];             // A_kc[m][j=r16]
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
         }
-        return f;
-      };
-      int t = wave;
-      frag cur;
-      if (t < ntiles) cur = load(lo, hi);
-      while (t < ntiles) {
-        const int clo = lo, chi = hi;
-        const bool more = t + LNW < ntiles;
-        if (more) coords(t + LNW);
-        const frag nxt = load(more ? lo : clo, more ? hi : chi);     // (unconditional: a re-read of this tile when it is the last)
-        // two independent accumulator chains (k-steps 0,1 and 2,3): a 4-deep chain of dependent MFMAs waits out the full
-        // pipeline latency three times
-        d4l_t acc = cur.acc, acc2 = {0.0, 0.0, 0.0, 0.0};
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.av[0], cur.bv[0], acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.av[2], cur.bv[2], acc2, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.av[1], cur.bv[1], acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.av[3], cur.bv[3], acc2, 0, 0, 0);
-        acc += acc2;
-        const int r0 = 16 * (k + 1 + clo), c0 = 16 * (k + 1 + chi);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) M[(r0 + g + 4 * q) + (c0 + r16) * LLD] = acc[q];
-        cur = nxt;
-        t += LNW;
+        for (int q = 0; q < 4; ++q) M[(k0 + g + 4 * q) + (c0 + r16) * LLD] = acc[q];
       }
+      __syncthreads();
+      LEAF_MARK();
+      // trailing: A_rc -= R_kr^T R_kc, k < r <= c, with one step of lookahead: wave 0 updates the next diagonal tile
+      // (pair 0 of the enumeration) and goes straight on to factor it -- the one-wave, latency-bound part of the next
+      // step -- while waves 1.. update the other tiles.  The operands of a wave's NEXT tile are read while the MFMAs of
+      // the current one run (a tile is only 4 MFMAs: unpipelined, LDS latency and accumulator round trip dominate).
+      {
+        const int nt = nk - 1 - k, ntiles = nt * (nt + 1) / 2;
+        // (lo, hi) of tile t from a per-lane table (lane t holds pair t of the triangular enumeration): one v_readlane
+        // instead of ~70 scalar instructions of index stepping per tile -- these loops are instruction-issue bound
+        int lo, hi;
+        auto coords = [&](int t_) { const int e = __builtin_amdgcn_readlane(tri_tab, t_ < 63 ? t_ : 63); lo = e & 15; hi = e >> 4; };
+        struct frag { d4l_t acc; double av[4], bv[4]; };
+        auto load = [&](int lo_, int hi_) {
+          frag f;
+          const int r0 = 16 * (k + 1 + lo_), c0 = 16 * (k + 1 + hi_);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) f.acc[q] = M[(r0 + g + 4 * q) + (c0 + r16) * LLD];
+#pragma unroll
+          for (int st = 0; st < 4; ++st) {
+            const int m = 4 * st + g;
+            f.av[st] = -M[(k0 + m) + (r0 + r16) * LLD];               // -R_kr[m][i=r16]
+            f.bv[st] = M[(k0 + m) + (c0 + r16) * LLD];                //  R_kc[m][j=r16]
+          }
+          return f;
+        };
+        const int stride = wave == 0 ? ntiles : LNW - 1;              // wave 0: tile 0 only; waves 1..: tiles 1, 2, ...
+        int t = wave == 0 ? 0 : wave;
+        coords(t);
+        frag cur;
+        if (t < ntiles) cur = load(lo, hi);
+        while (t < ntiles) {
+          const int clo = lo, chi = hi;
+          const bool more = t + stride < ntiles;
+          if (more) coords(t + stride);
+          const frag nxt = load(more ? lo : clo, more ? hi : chi);     // (unconditional: a re-read of this tile when it is the last)
+          // two independent accumulator chains (k-steps 0,1 and 2,3)
+          d4l_t acc = cur.acc, acc2 = {0.0, 0.0, 0.0, 0.0};
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.av[0], cur.bv[0], acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.av[2], cur.bv[2], acc2, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.av[1], cur.bv[1], acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.av[3], cur.bv[3], acc2, 0, 0, 0);
+          acc += acc2;
+          const int r0 = 16 * (k + 1 + clo), c0 = 16 * (k + 1 + chi);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) M[(r0 + g + 4 * q) + (c0 + r16) * LLD] = acc[q];
+          cur = nxt;
+          t += stride;
+        }
+        if (wave == 0) leaf_diag_mfma<false>(M, Vs, k + 1, lane, false, info, info_base, b);   // same wave wrote the tile
+      }
+      __syncthreads();
+      LEAF_MARK();
     }
-    __syncthreads();
-    LEAF_MARK();
   }
 
   if (!invert_only) leaf_store_upper(M, A, lda, b, zero_lower, tid);
@@ -474,8 +479,8 @@ int leaf_launch(capi_handle_t h, double* A, int64_t lda, double* X, int64_t ldx,
       CAPI_HIP_CHECK(h, hipMemcpy(t, dbg, sizeof(t), hipMemcpyDeviceToHost));
       CAPI_HIP_CHECK(h, hipFree(dbg));
       fprintf(stderr, "[leaf b=%d]", b);
-      for (int i = 1; i < 33; ++i) fprintf(stderr, " %lld", t[i] - t[i - 1]);
-      fprintf(stderr, "  total %lld\n", t[32] - t[0]);
+      for (int i = 1; i < 26; ++i) fprintf(stderr, " %lld", t[i] - t[i - 1]);
+      fprintf(stderr, "  total %lld\n", t[25] - t[0]);
 
     }
   }

@@ -608,36 +608,42 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
     CAPI_HIP_CHECK(h, hipGetLastError());
     return CAPI_OK;
   }
-  // Choose tile size and split-K from a small cost model (all in microseconds, MFMA-bound regime):
-  //   a CU runs 2 workgroups of 128-tiles or 4 of 64-tiles; with the CU fully subscribed one k-panel (16) of a tile costs
-  //   64 MFMA * 64 cycles * 2 (128) or 16 * 64 * 4 (64) cycles, i.e. the same area rate -- so the choice is about ROUNDS:
-  //   time = ceil(tiles * s / slots) * tile_time(K / s) + reduce(s).  Splitting K trades a partial last round for a slab pass.
+  // Choose tile size and split-K from a small cost model in CU-cycles.  One k-panel (16 deep) of a 128-tile keeps all
+  // four MFMA pipes of a CU busy for 64 MFMAs x 64 cycles = 4096 cycles, of a 64-tile for 1024; co-resident workgroups
+  // share the pipes, so a CU works through the tiles dealt to it at that rate whatever their number.  The makespan is
+  // the busiest CU's queue: ceil(tiles / CUs) equal tiles, or for TRMM (k-range grows linearly along the triangular
+  // dimension, longest-first dealing) the larger of the mean load and the single longest tile.
   const bool tri = p.tri_side >= 0;
-  const double us_per_k16_128 = 8192.0 / 2200.0, us_per_k16_64 = 4096.0 / 2200.0;   // at ~2.2 GHz
+  const double ghz = 2.35;
   double best = 1e300;
   int best_ts = 128, best_s = 1;
   static const char* force_ts = getenv("CAPI_FORCE_TS");
   for (int ts : {128, 64}) {
     if (force_ts && atoi(force_ts) != ts) continue;
     const double nt = (double)count_tiles(p, ts);
-    const double slots = (ts == 128 ? 2.0 : 4.0) * h->num_cu;
-    const double keff = tri ? 0.5 * p.K + 0.5 * ts : (double)p.K;       // average k-range of a TRMM tile
-    const int spc = ts == 128 ? 2 : 4;                                   // resident workgroups per CU
+    const double cyc = ts == 128 ? 4096.0 : 1024.0;
+    const double eff = ts == 128 ? 0.89 : 0.80;          // measured pipe utilisation of the two kernels (fast path)
+    const int ncu = h->num_cu;
     for (int sk = 1; sk <= 512; ++sk) {
       if (sk > 1 && (!ws_for_slab || p.K / sk < 256)) break;
-      // full rounds at full subscription, then a last round in which the busiest CU holds ceil(rem / CUs) workgroups
-      // (a workgroup alone on a CU runs spc times faster than at full subscription)
-      const int64_t units = (int64_t)nt * sk, full = units / (int64_t)slots, rem = units - full * (int64_t)slots;
-      const double rounds = (double)full + (double)cdiv(rem, h->num_cu) / spc;
-      const double share = 1.0;
-      // the 64-tile kernel pays twice the LDS/L2 traffic and barriers per flop: measured a few % slower at equal rounds
-      double t = rounds * share * (keff / sk / 16.0) * (ts == 128 ? us_per_k16_128 : 1.06 * us_per_k16_64) + 6.0;
+      double busiest;                                     // cycles of work queued on the busiest CU
+      if (!tri) {
+        busiest = (double)cdiv((int64_t)nt * sk, ncu) * ((double)p.K / sk / 16.0) * cyc;
+      } else {
+        const double kmax = (double)p.K / sk, kavg = (0.5 * p.K + 0.5 * ts) / sk;
+        const double mean = nt * sk * (kavg / 16.0) * cyc / ncu, longest = (kmax / 16.0) * cyc;
+        busiest = mean * 1.08 > longest ? mean * 1.08 : longest;
+      }
+      double t = busiest / (ghz * 1e3 * eff) + 7.0;
       // operand panels stream from L2/MALL: ~4 TB/s effective when every tile re-reads its two panels
       // (a syrk's diagonal tiles stage one panel; a TRMM's triangular operand is small and stays cache resident)
+      const double keff = tri ? 0.5 * p.K + 0.5 * ts : (double)p.K;
       const double panels = (p.out_uplo >= 0 && p.A == p.B) ? 2.0 * nt - (double)cdiv(p.N, ts) : (tri ? 1.0 * nt : 2.0 * nt);
-      const double t_mem = panels * ts * keff * 8.0 / 4.0e6;
+      // (operands that fit the 256 MB Infinity Cache are re-read from there at roughly twice the HBM-side rate)
+      const double footprint = ((p.A == p.B ? 0.0 : (double)p.M) + (double)p.N) * (double)p.K * 8.0;
+      const double t_mem = panels * ts * keff * 8.0 / (footprint <= 192.0e6 ? 8.0e6 : 4.0e6);
       if (t_mem > t) t = t_mem;
-      if (sk > 1) t = 1.03 * t + 6.0 + (double)(sk + 2) * (double)p.M * (double)p.N * (p.out_uplo >= 0 ? 0.5 : 1.0) * 8.0 / 2.5e6;
+      if (sk > 1) t = 1.12 * t + 6.0 + (double)(sk + 2) * (double)p.M * (double)p.N * (p.out_uplo >= 0 ? 0.5 : 1.0) * 8.0 / 2.5e6;
       if (t < best) { best = t; best_ts = ts; best_s = sk; }
     }
   }

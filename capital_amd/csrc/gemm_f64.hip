@@ -52,6 +52,8 @@ struct GemmArgs {
   int tri_unit;
   int a_vec, b_vec;   // 16-byte loads legal for A / B
   int splitk, k_per_split;
+  int k_interleave;   // split-K slices are interleaved panel by panel (slice z owns panels z, z+splitk, ...) instead of contiguous
+  int k_rotate;       // split-K slice z starts its k-loop z/splitk of the way through its range and wraps around
   double* slab;       // split-K partial sums: slab[z*slab_stride + i + j*slab_ld]
   int64_t slab_ld, slab_stride;
   int tiles_m, tiles_n, ntiles;
@@ -266,11 +268,20 @@ __global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel
   } else if (p.tri_side == CAPI_RIGHT) {
     if (p.tri_eff_upper) khi = min(p.K, j0 + BN); else klo = j0;
   }
+  // kstep: distance between the panels this workgroup multiplies.  Interleaved split-K (no triangular operand) makes
+  // the slices that are resident together read neighbouring rows of a tall operand: a few sequential DRAM streams and
+  // shared L2 lines instead of tiles x slices scattered ones.
+  int kstep = BK;
   if (p.splitk > 1) {
-    klo = max(klo, z * p.k_per_split);
-    khi = min(khi, (z + 1) * p.k_per_split);
+    if (p.k_interleave) {
+      klo = z * BK;
+      kstep = p.splitk * BK;
+    } else {
+      klo = max(klo, z * p.k_per_split);
+      khi = min(khi, (z + 1) * p.k_per_split);
+    }
   }
-  const int ntk = khi > klo ? (khi - klo + BK - 1) / BK : 0;
+  const int ntk = khi > klo ? (khi - klo + kstep - 1) / kstep : 0;
   const bool maskA = p.tri_side == CAPI_LEFT, maskB = p.tri_side == CAPI_RIGHT;
   const bool shareB = AK == BKC && p.share_ab && ti == tj;   // B panel == A panel: load and stage it once
   const bool keep_ge = (p.tri_side == CAPI_LEFT) == (p.tri_eff_upper != 0);
@@ -288,7 +299,7 @@ __global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel
   const double* fb = BKC ? p.B + (int64_t)(j0 + (tid >> 3)) * p.ldb + klo + 2 * (tid & 7)
                          : p.B + (int64_t)(klo + tid / (TS / 2)) * p.ldb + j0 + 2 * (tid & (TS / 2 - 1));
   const int64_t qsa = AK ? 32 * p.lda : (512 / TS) * p.lda, qsb = BKC ? 32 * p.ldb : (512 / TS) * p.ldb;
-  const int64_t ksa = AK ? BK : BK * p.lda, ksb = BKC ? BK : BK * p.ldb;
+  const int64_t ksa = AK ? kstep : (int64_t)kstep * p.lda, ksb = BKC ? kstep : (int64_t)kstep * p.ldb;
 
   // triangular output: on a diagonal tile the sub-tiles lying entirely in the unwanted triangle are never computed
   unsigned out_keep = (1u << (SUB * SUB)) - 1u;
@@ -303,10 +314,15 @@ __global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel
       }
   }
 
+  // Rotation (split-K without a triangular operand): every slice of a tall operand walks rows that sit a multiple of
+  // the slice length apart -- a power of two times 128 bytes in practice, so all slices would sweep the SAME memory
+  // channel at the same moment and move on together.  Slice z starts z/splitk of the way through and wraps.
+  const int rot = (p.k_rotate && p.splitk > 1 && ntk > 1) ? (int)((int64_t)z * ntk / p.splitk) : 0;
+  const int kfirst = klo + rot * kstep;
   d2_t ra[NQ], rb[NQ];
   if (ntk > 0) {
-    panel_load<TS, AK>(p.A, p.lda, i0, p.M, klo, khi, tid, p.a_vec, ra);
-    if (!shareB) panel_load<TS, BKC>(p.B, p.ldb, j0, p.N, klo, khi, tid, p.b_vec, rb);
+    panel_load<TS, AK>(p.A, p.lda, i0, p.M, kfirst, khi, tid, p.a_vec, ra);
+    if (!shareB) panel_load<TS, BKC>(p.B, p.ldb, j0, p.N, kfirst, khi, tid, p.b_vec, rb);
     if (maskA && klo < i0 + BM && klo + BK > i0) panel_mask<TS, AK>(i0, klo, tid, keep_ge, p.tri_unit, ra);
     if (maskB && klo < j0 + BN && klo + BK > j0) panel_mask<TS, BKC>(j0, klo, tid, keep_ge, p.tri_unit, rb);
     panel_store<TS, AK>(lds, tid, ra);
@@ -318,12 +334,13 @@ __global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel
   // FAST iterations (interior tile, successor panel entirely in range) are a loop of their own: sharing one loop with
   // the predicated loads made the register allocator keep two copies of the staging registers and wait for the
   // prefetch (s_waitcnt vmcnt) BEFORE the MFMA phase to reconcile them -- the load latency it was meant to hide.
-  auto iterate = [&](const int t, auto fast_tag) {
+  int par = 0;                              // LDS stage holding the panel being multiplied
+  auto iterate = [&](const int t, const int tnext, auto fast_tag) {
     constexpr bool FAST = decltype(fast_tag)::value;
-    const double* La = lds + (t & 1) * STAGE_LDS;
+    const double* La = lds + par * STAGE_LDS;
     const double* Lb = shareB ? La : La + TILE_LDS;
-    const int kn = klo + (t + 1) * BK;
-    const bool more = FAST || (t + 1 < ntk);
+    const int kn = klo + tnext * kstep;
+    const bool more = FAST || (tnext >= 0);
     if (FAST) {
       fa += ksa;
       fb += ksb;
@@ -338,7 +355,7 @@ __global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel
     unsigned keep = (1u << (SUB * SUB)) - 1u;
     if (!FAST) {
       keep = out_keep;
-      const int kk = klo + t * BK;
+      const int kk = klo + t * kstep;
       // only panels that cross the diagonal band of this tile can have dead sub-tiles
       const bool band = p.tri_side == CAPI_LEFT ? (kk < i0 + BM && kk + BK > i0) : (kk < j0 + BN && kk + BK > j0);
       if (p.tri_side >= 0 && band && !p.no_skip) {
@@ -375,32 +392,46 @@ __global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel
         if (maskA && kn < i0 + BM && kn + BK > i0) panel_mask<TS, AK>(i0, kn, tid, keep_ge, p.tri_unit, ra);
         if (maskB && kn < j0 + BN && kn + BK > j0) panel_mask<TS, BKC>(j0, kn, tid, keep_ge, p.tri_unit, rb);
       }
-      double* Na = lds + ((t + 1) & 1) * STAGE_LDS;
+      double* Na = lds + (par ^ 1) * STAGE_LDS;
       panel_store<TS, AK>(Na, tid, ra);
       if (!shareB) panel_store<TS, BKC>(Na + TILE_LDS, tid, rb);
     }
+    par ^= 1;
     __syncthreads();
   };
   // Iterations t in [0, nfast) have an interior successor panel.  Of those, FAST ones must also have every sub-tile live
   // (not a diagonal tile of a triangular output) and keep clear of the band [tb0, tb1) of panels that cross the diagonal
   // of a triangular operand -- both as the panel multiplied (t) and as the panel staged (t + 1).
-  const int nfast = (interior && !(p.out_uplo >= 0 && ti == tj)) ? (khi - klo) / BK - 1 : 0;
+  // FAST iteration t needs its successor panel [klo + (t+1) kstep, + BK) inside [klo, khi)
+  // (diagonal tiles of a triangular output take it too: computing their dead sub-tiles in the lean loop is cheaper than
+  //  skipping them in the generic one -- the wave holding 16 live sub-tiles sets the pace either way)
+  const int nfast = (interior && khi - klo >= BK) ? (khi - klo - BK) / kstep : 0;
   int tb0 = ntk, tb1 = ntk;                 // no band
   if (p.tri_side >= 0) {
     const int d0 = p.tri_side == CAPI_LEFT ? i0 : j0;
     tb0 = d0 > klo ? (d0 - klo) / BK : 0;
     tb1 = d0 + TS > klo ? (d0 + TS - klo + BK - 1) / BK : 0;
   }
-  int t = 0;
-  while (t < ntk) {
-    const int fe = t + 1 < tb0 ? min(tb0 - 1, nfast) : (t >= tb1 ? nfast : t);
-    for (; t < fe; ++t) iterate(t, std::true_type{});
-    // fa/fb advance only in FAST iterations; the generic ones derive their addresses from (i0, j0, kn) -- resynchronise
-    const int ge = (t < tb1 && tb1 < nfast) ? tb1 : ntk;
-    const int t_in = t;
-    for (; t < ge; ++t) iterate(t, std::false_type{});
-    fa += (int64_t)(t - t_in) * ksa;
-    fb += (int64_t)(t - t_in) * ksb;
+  // two segments of the panel sequence: [rot, ntk) then (after the wrap) [0, rot); without rotation the second is empty
+  const double* const fa0 = fa;
+  const double* const fb0 = fb;
+  for (int seg = 0; seg < 2; ++seg) {
+    const int tb = seg == 0 ? rot : 0, te = seg == 0 ? ntk : rot;
+    const int after = (seg == 0 && rot > 0) ? 0 : -1;     // successor of the segment's last iteration
+    fa = fa0 + (int64_t)tb * ksa;
+    fb = fb0 + (int64_t)tb * ksb;
+    const int lim = min(nfast, te - 1);                   // a FAST iteration's successor is t + 1, inside the segment
+    int t = tb;
+    while (t < te) {
+      const int fe = t + 1 < tb0 ? min(tb0 - 1, lim) : (t >= tb1 ? lim : t);
+      for (; t < fe; ++t) iterate(t, t + 1, std::true_type{});
+      // fa/fb advance only in FAST iterations; the generic ones derive their addresses from (i0, j0, kn) -- resynchronise
+      const int ge = (t < tb1 && tb1 < lim) ? tb1 : te;
+      const int t_in = t;
+      for (; t < ge; ++t) iterate(t, t + 1 < te ? t + 1 : after, std::false_type{});
+      fa += (int64_t)(t - t_in) * ksa;
+      fb += (int64_t)(t - t_in) * ksb;
+    }
   }
 
   // epilogue: lane holds C[i = ..+r16][j = ..+g+4*reg]; 16 lanes -> 128 contiguous bytes of one column
@@ -628,7 +659,13 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
       if (sk > 1 && (!ws_for_slab || p.K / sk < 256)) break;
       double busiest;                                     // cycles of work queued on the busiest CU
       if (!tri) {
-        busiest = (double)cdiv((int64_t)nt * sk, ncu) * ((double)p.K / sk / 16.0) * cyc;
+        // a CU keeps `res` workgroups resident; the last, partially filled group of its queue runs without partners to
+        // cover its barrier and load stalls (measured ~0.7x the paired rate for a lone 128-tile workgroup)
+        const int64_t q = cdiv((int64_t)nt * sk, ncu);
+        const int res = ts == 128 ? 2 : 4;
+        const int64_t lone = q % res;
+        const double per = ((double)p.K / sk / 16.0) * cyc;
+        busiest = (double)(q - lone) * per + (double)lone * per / (lone == 0 ? 1.0 : (0.62 + 0.38 * (double)lone / res));
       } else {
         const double kmax = (double)p.K / sk, kavg = (0.5 * p.K + 0.5 * ts) / sk;
         const double mean = nt * sk * (kavg / 16.0) * cyc / ncu, longest = (kmax / 16.0) * cyc;
@@ -692,6 +729,8 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
   p.share_ab = (p.out_uplo >= 0 && p.A == p.B && p.lda == p.ldb && ak == bkc && !getenv("CAPI_NO_SHARE")) ? 1 : 0;
   p.splitk = 1;
   p.k_per_split = p.K;
+  p.k_interleave = 0;
+  p.k_rotate = 0;
   p.slab = nullptr;
   p.slab_ld = p.slab_stride = 0;
   if (best_s > 1) {
@@ -700,6 +739,8 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
     if (sk > 1) {
       p.splitk = (int)sk;
       p.k_per_split = (int)kps;
+      p.k_interleave = (!tri && getenv("CAPI_INTERLEAVE")) ? 1 : 0;
+      p.k_rotate = (!tri && !p.k_interleave && !getenv("CAPI_NO_ROTATE")) ? 1 : 0;
       p.slab_ld = p.M;
       p.slab_stride = (int64_t)p.M * p.N;
       void* ws;

@@ -616,6 +616,267 @@ gemm_kernel_t pick_small(bool ak, bool bkc) {
 
 
 
+// ---- tall-skinny operands (CholeskyQR2: m x n with n <= 256 and m in the millions) --------------------------------
+// With n this small a square tiling re-reads the tall operand once per tile column (Gram: 3 x 128-tiles = 3 passes over
+// 8.6 GB, Q = A R^-1 with 64-tiles: 2.5 passes) and that, not the matrix pipe, sets the time.  Here one workgroup of 8
+// waves covers the FULL width, so every element of the tall operand travels global -> LDS exactly once.
+constexpr int TSK_THREADS = 512, TSK_W = 256;    // up to 16 column strips of 16
+
+// Gram matrix, upper triangle:  slab[z] (or C) = sum over this workgroup's k-range of A[k][i] A[k][j], A k-contiguous.
+// The 16 x 16 grid of output tiles has 136 upper tiles; wave w owns tile-rows w and 15-w (17 tiles): balanced, and per
+// k-step it reads 2 row fragments and the <= 16 column fragments right of its shorter row.
+// FULLW: all 16 column strips exist (n == 256): no per-tile liveness test, i.e. no branch between MFMAs
+template <int W, bool FULLW>
+__device__ __forceinline__ void gram_ts_body(const GemmArgs& p, double* __restrict__ lds) {
+  constexpr int STAGE = TSK_W * SK;                        // [col][k], k-contiguous + 2 pad (as the tile kernel's Lk)
+  constexpr int RA = W, RB = 15 - W, NA = 16 - RA;         // tile-rows of this wave; row RA holds NA tiles, row RB holds W + 1
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int N = p.N, nct = (N + 15) >> 4;
+  const int z = blockIdx.x, S = gridDim.x;
+  const int P = (p.K + BK - 1) / BK;                       // panels of the whole k-range
+  const int pb = (int)((int64_t)z * P / S), pe = (int)((int64_t)(z + 1) * P / S), np = pe - pb;
+  const int rot = np > 1 ? (int)((int64_t)z * np / S) : 0; // staggered start: resident slices do not sweep DRAM channels in step
+  d4_t acc[17];
+#pragma unroll
+  for (int q = 0; q < 17; ++q) acc[q] = (d4_t){0.0, 0.0, 0.0, 0.0};
+
+  const int kp = tid & 7, c0 = tid >> 3;                   // this thread's pieces: columns c0 + 64 q, k = 2 kp (+1)
+  // load() only ISSUES the loads (unconditional, from a clamped address); every select on their results waits until
+  // stage(), after the MFMA phase -- a select right behind the load would make the wave wait for the prefetch up front
+  auto load = [&](int pnl, d2_t (&st)[4]) {
+    const int k = pnl * BK + 2 * kp;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = c0 + 64 * q;
+      const bool in = c < N && k + 1 < p.K && p.a_vec;
+      st[q] = *(const d2_t*)(in ? p.A + (int64_t)c * p.lda + k : p.A);
+    }
+  };
+  auto stage = [&](double* L, int pnl, const d2_t (&st)[4]) {
+    const int k = pnl * BK + 2 * kp;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = c0 + 64 * q;
+      const bool in = c < N && k + 1 < p.K && p.a_vec;
+      d2_t v = st[q];
+      if (!in) {                                            // ragged edge / unaligned operand: scalar reads, rare
+        v = (d2_t){0.0, 0.0};
+        if (c < N) {
+          const double* ptr = p.A + (int64_t)c * p.lda + k;
+          if (k < p.K) v.x = ptr[0];
+          if (k + 1 < p.K) v.y = ptr[1];
+        }
+      }
+      *(d2_t*)&L[c * SK + 2 * kp] = v;
+    }
+  };
+  auto pidx = [&](int i) { int q = rot + i; if (q >= np) q -= np; return pb + q; };
+  // Two panels are in flight in registers beyond the one being multiplied: with one workgroup per CU the HBM latency
+  // under this access pattern (256 streams 32 MB apart) exceeds one iteration, and one panel ahead left ~35 % exposed.
+  d2_t stA[4], stB[4];
+  int par = 0;
+  auto step = [&](int it, d2_t (&cur)[4], d2_t (&nw)[4]) {   // cur holds panel it+1, nw receives panel it+2
+    const double* L = lds + par * STAGE;
+    if (it + 2 < np) load(pidx(it + 2), nw);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      d2_t bf[16];
+#pragma unroll
+      for (int j = RA; j < 16; ++j) bf[j] = *(const d2_t*)&L[(16 * j + r16) * SK + 8 * u + 2 * g];
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        // row RA: tiles (RA, j), j = RA..15 -> acc[j - RA];  row RB: tiles (RB, j), j = RB..15 -> acc[NA + j - RB]
+#pragma unroll
+        for (int j = RA; j < 16; ++j)
+          if (FULLW || j < nct) acc[j - RA] = __builtin_amdgcn_mfma_f64_16x16x4f64(e ? bf[j].y : bf[j].x, e ? bf[RA].y : bf[RA].x, acc[j - RA], 0, 0, 0);
+#pragma unroll
+        for (int j = RB; j < 16; ++j)
+          if (FULLW || j < nct) acc[NA + j - RB] = __builtin_amdgcn_mfma_f64_16x16x4f64(e ? bf[j].y : bf[j].x, e ? bf[RB].y : bf[RB].x, acc[NA + j - RB], 0, 0, 0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+    }
+    if (it + 1 < np) stage(lds + (par ^ 1) * STAGE, pidx(it + 1), cur);
+    par ^= 1;
+    __syncthreads();
+  };
+  if (np > 0) {
+    load(pidx(0), stA);
+    if (np > 1) load(pidx(1), stB);
+    stage(lds, pidx(0), stA);
+  }
+  __syncthreads();
+  for (int it = 0; it < np; it += 2) {
+    step(it, stB, stA);
+    if (it + 1 < np) step(it + 1, stA, stB);
+  }
+  // epilogue: lane holds (i = 16 row + r16, j = 16 col + g + 4 reg); partial sums go to slab z, or straight to C
+  auto put = [&](int trow, int tcol, const d4_t& v) {
+    const int i = 16 * trow + r16;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int j = 16 * tcol + g + 4 * reg;
+      if (i < N && j < N && i <= j) {
+        if (p.splitk > 1) p.slab[(int64_t)z * p.slab_stride + i + (int64_t)j * p.slab_ld] = v[reg];
+        else {
+          double* c = p.C + i + (int64_t)j * p.ldc;
+          double r = p.alpha * v[reg];
+          if (p.beta != 0.0) r += p.beta * (*c);
+          *c = r;
+        }
+      }
+    }
+  };
+#pragma unroll
+  for (int j = RA; j < 16; ++j) if (j < nct) put(RA, j, acc[j - RA]);
+#pragma unroll
+  for (int j = RB; j < 16; ++j) if (j < nct) put(RB, j, acc[NA + j - RB]);
+}
+
+__global__ __launch_bounds__(TSK_THREADS, 1) void gram_ts_kernel(const GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  // the tile-to-wave map is baked into eight instantiations (accumulators must be indexed at compile time); all of them
+  // execute the same sequence of barriers
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (p.N == TSK_W) {
+    switch (w) {
+      case 0: gram_ts_body<0, true>(p, lds); break;
+      case 1: gram_ts_body<1, true>(p, lds); break;
+      case 2: gram_ts_body<2, true>(p, lds); break;
+      case 3: gram_ts_body<3, true>(p, lds); break;
+      case 4: gram_ts_body<4, true>(p, lds); break;
+      case 5: gram_ts_body<5, true>(p, lds); break;
+      case 6: gram_ts_body<6, true>(p, lds); break;
+      default: gram_ts_body<7, true>(p, lds); break;
+    }
+  } else {
+    switch (w) {
+      case 0: gram_ts_body<0, false>(p, lds); break;
+      case 1: gram_ts_body<1, false>(p, lds); break;
+      case 2: gram_ts_body<2, false>(p, lds); break;
+      case 3: gram_ts_body<3, false>(p, lds); break;
+      case 4: gram_ts_body<4, false>(p, lds); break;
+      case 5: gram_ts_body<5, false>(p, lds); break;
+      case 6: gram_ts_body<6, false>(p, lds); break;
+      default: gram_ts_body<7, false>(p, lds); break;
+    }
+  }
+}
+
+// Q = alpha * A * T (+ beta * C) for a tall A (M x 256, row-contiguous) and a 256 x 256 UPPER triangular T.
+// T-stationary: wave w of the 8 keeps the MFMA fragments of output strips w and 15-w (16 columns each; 4 (w+1) + 4 (16-w)
+// = 68 k-steps, the same for every wave) in registers for the whole kernel.  A streams through LDS in 16-row tiles
+// (32 KB, read from HBM exactly once, two tiles in flight in registers beyond the one being multiplied); per tile a wave
+// reads each A fragment once and issues its 68 MFMAs with no barrier in between; each wave stores its own two strips.
+// Work per tile is uniform, so the one barrier per tile (8704 MFMA cycles) costs what it costs in the Gram kernel.
+// (A row-split variant that staged T's panels through LDS instead spent its time on T reloads, on short late panels and
+//  on `s_waitcnt vmcnt(0)` forced by mixing outstanding stores and loads: 8-9.6 ms against 7.6 ms for the tile kernel.)
+template <int W>
+__device__ __forceinline__ void trmm_ts_body(const GemmArgs& p, double* __restrict__ lds) {
+  constexpr int SA = W, SB = 15 - W, NA = 4 * (SA + 1), NB = 4 * (SB + 1);   // strips and their k-step counts (NA <= NB)
+  constexpr int TILE = 256 * 16;                           // LDS tile [k][16 rows]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int ntile = (p.M + 15) >> 4;
+  // stationary T fragments: k-step s supplies T[4 s + g][16 strip + r16] (zero below the diagonal, unit diagonal on request)
+  double ta[NA], tb[NB];
+  auto tget = [&](int k, int j) {
+    double v = p.B[k + (int64_t)j * p.ldb];
+    if (k > j) v = 0.0;
+    if (p.tri_unit && k == j) v = 1.0;
+    return v;
+  };
+#pragma unroll
+  for (int s_ = 0; s_ < NA; ++s_) ta[s_] = tget(4 * s_ + g, 16 * SA + r16);
+#pragma unroll
+  for (int s_ = 0; s_ < NB; ++s_) tb[s_] = tget(4 * s_ + g, 16 * SB + r16);
+
+  // A tile -> registers: thread t owns k = t >> 1 and rows 8 (t & 1) .. +7 (64 contiguous bytes)
+  const int lk = tid >> 1, lh = tid & 1;
+  auto load = [&](int tile, d2_t (&st)[4]) {
+    const int row0 = 16 * tile + 8 * lh;
+    const bool in = row0 + 8 <= p.M && p.a_vec;
+    const double* src = in ? p.A + row0 + (int64_t)lk * p.lda : p.A;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) st[q] = *(const d2_t*)(src + 2 * q);
+  };
+  auto stage = [&](double* L, int tile, const d2_t (&st)[4]) {
+    const int row0 = 16 * tile + 8 * lh;
+    const bool in = row0 + 8 <= p.M && p.a_vec;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      d2_t v = st[q];
+      if (!in) {                                            // ragged last tile / unaligned A: scalar reads
+        const int r = row0 + 2 * q;
+        v = (d2_t){0.0, 0.0};
+        if (r < p.M) v.x = p.A[r + (int64_t)lk * p.lda];
+        if (r + 1 < p.M) v.y = p.A[r + 1 + (int64_t)lk * p.lda];
+      }
+      *(d2_t*)&L[lk * 16 + 8 * lh + 2 * q] = v;
+    }
+  };
+  const int t0 = blockIdx.x, dt = gridDim.x;
+  if (t0 >= ntile) return;
+  d2_t stA[4], stB[4];
+  int par = 0;
+  auto step = [&](int tile, d2_t (&cur)[4], d2_t (&nw)[4]) {   // cur holds tile + dt, nw receives tile + 2 dt
+    const double* L = lds + par * TILE;
+    if (tile + 2 * dt < ntile) load(tile + 2 * dt, nw);
+    d4_t ca = {0.0, 0.0, 0.0, 0.0}, cb = {0.0, 0.0, 0.0, 0.0};
+    const double* la = L + g * 16 + r16;                    // A[row r16][k = 4 s + g]
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s_ = 0; s_ < NB; ++s_) {
+      const double af = la[64 * s_];
+      if (s_ < NA) ca = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[s_], af, ca, 0, 0, 0);
+      cb = __builtin_amdgcn_mfma_f64_16x16x4f64(tb[s_], af, cb, 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if (tile + dt < ntile) stage(lds + (par ^ 1) * TILE, tile + dt, cur);
+    par ^= 1;
+    __syncthreads();
+    // lane holds (i = row r16 of the tile, j = 16 strip + g + 4 reg): 16 lanes -> 128 contiguous bytes of one column
+    const int i = 16 * tile + r16;
+    if (i < p.M) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const d4_t& v = half ? cb : ca;
+        double* c = p.C + i + (int64_t)(16 * (half ? SB : SA) + g) * p.ldc;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          double r = p.alpha * v[reg];
+          if (p.beta != 0.0) r += p.beta * (*c);
+          *c = r;
+          c += 4 * p.ldc;
+        }
+      }
+    }
+  };
+  load(t0, stA);
+  if (t0 + dt < ntile) load(t0 + dt, stB);
+  stage(lds, t0, stA);
+  __syncthreads();
+  for (int tile = t0; tile < ntile; tile += 2 * dt) {
+    step(tile, stB, stA);
+    if (tile + dt < ntile) step(tile + dt, stA, stB);
+  }
+}
+
+__global__ __launch_bounds__(TSK_THREADS, 1) void trmm_right_ts_kernel(const GemmArgs p) {   // N == K == 256
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
+    case 0: trmm_ts_body<0>(p, lds); break;
+    case 1: trmm_ts_body<1>(p, lds); break;
+    case 2: trmm_ts_body<2>(p, lds); break;
+    case 3: trmm_ts_body<3>(p, lds); break;
+    case 4: trmm_ts_body<4>(p, lds); break;
+    case 5: trmm_ts_body<5>(p, lds); break;
+    case 6: trmm_ts_body<6>(p, lds); break;
+    default: trmm_ts_body<7>(p, lds); break;
+  }
+}
+
 template <int TS>
 gemm_kernel_t pick_kernel(bool ak, bool bkc) {
   return ak ? (bkc ? dgemm_tile_kernel<TS, true, true> : dgemm_tile_kernel<TS, true, false>)
@@ -638,6 +899,60 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
     hipLaunchKernelGGL(scale_kernel, grid, dim3(256), 0, s, p.C, p.ldc, p.M, p.N, p.beta, p.out_uplo);
     CAPI_HIP_CHECK(h, hipGetLastError());
     return CAPI_OK;
+  }
+  // tall-skinny right-TRMM (Q = A R^-1): persistent full-width workgroups, A read once
+  {
+    static const bool no_ts2 = getenv("CAPI_NO_TS") != nullptr;
+    if (!no_ts2 && p.tri_side == CAPI_RIGHT && p.tri_eff_upper && !ak && bkc && p.N == TSK_W && p.K == p.N &&
+        (int64_t)p.M >= 64 * (int64_t)p.N) {
+      p.a_vec = (((uintptr_t)p.A & 15) == 0) && ((p.lda & 1) == 0);
+      p.splitk = 1;
+      const int ntile = (int)cdiv(p.M, 16);
+      const int grid = ntile < h->num_cu ? ntile : h->num_cu;
+      const size_t lds_bytes = sizeof(double) * 2 * 256 * 16;
+      void (*k)(const GemmArgs) = trmm_right_ts_kernel;
+      static bool attr_set = false;
+      if (!attr_set) {
+        CAPI_HIP_CHECK(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(TSK_THREADS), lds_bytes, s, p);
+      CAPI_HIP_CHECK(h, hipGetLastError());
+      return CAPI_OK;
+    }
+  }
+  // tall-skinny Gram matrix: full-width workgroups, the tall operand is read once
+  {
+    static const bool no_ts = getenv("CAPI_NO_TS") != nullptr;
+    if (!no_ts && p.out_uplo == CAPI_UPPER && p.tri_side < 0 && ak && bkc && p.A == p.B && p.lda == p.ldb && p.N <= TSK_W &&
+        p.N >= 64 && (int64_t)p.K >= 64 * (int64_t)p.N && ws_for_slab) {
+      const int64_t P = cdiv(p.K, BK);
+      int S = (int)(P / 32 < h->num_cu ? (P / 32 > 0 ? P / 32 : 1) : h->num_cu);       // one resident workgroup per CU
+      p.a_vec = (((uintptr_t)p.A & 15) == 0) && ((p.lda & 1) == 0);
+      p.splitk = S;
+      p.slab = nullptr; p.slab_ld = p.N; p.slab_stride = (int64_t)p.N * p.N;
+      if (S > 1) {
+        void* ws;
+        int rc = capi_ws_get(h, sizeof(double) * (size_t)p.slab_stride * (size_t)S, &ws);
+        if (rc != CAPI_OK) return rc;
+        p.slab = (double*)ws;
+      }
+      const size_t lds_bytes = sizeof(double) * 2 * TSK_W * SK;
+      static bool attr_set = false;
+      if (!attr_set) {
+        CAPI_HIP_CHECK(h, hipFuncSetAttribute((const void*)gram_ts_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(gram_ts_kernel, dim3((unsigned)S), dim3(TSK_THREADS), lds_bytes, s, p);
+      CAPI_HIP_CHECK(h, hipGetLastError());
+      if (S > 1) {
+        dim3 grid((unsigned)cdiv(p.M, 256), (unsigned)(p.N < 65535 ? p.N : 65535));
+        hipLaunchKernelGGL(splitk_reduce_kernel, grid, dim3(256), 0, s, p.slab, p.slab_ld, p.slab_stride, p.splitk, p.C, p.ldc,
+                           p.M, p.N, p.alpha, p.beta, p.out_uplo);
+        CAPI_HIP_CHECK(h, hipGetLastError());
+      }
+      return CAPI_OK;
+    }
   }
   // Choose tile size and split-K from a small cost model in CU-cycles.  One k-panel (16 deep) of a 128-tile keeps all
   // four MFMA pipes of a CU busy for 64 MFMAs x 64 cycles = 4096 cycles, of a 64-tile for 1024; co-resident workgroups

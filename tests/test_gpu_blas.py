@@ -165,3 +165,33 @@ def test_dtrsm(hip, oracle, side, uplo, trans, diag, m, n):
     hip.call("capi_dtrsm", side, uplo, trans, diag, m, n, 0.5, capi.ptr(dT), nt, capi.ptr(dB), m)
     got = capi.to_host(dB)
     assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,n,pad", [(20037, 256, 3), (65536, 256, 0), (30001, 192, 2), (16384 + 16, 256, 0)])
+def test_tall_skinny_gram_and_right_trmm(m, n, pad):
+    """The full-width tall-skinny kernels (Gram = capi_dsyrk with K = m >> n; Q = A T = capi_dtrmm_oop Right/Upper,
+    cacqr.hpp:14-15,24-25) against a plain fp64 torch reference; ragged m, odd leading dimension, n below 256 (which
+    falls back to the tile kernel for the TRMM).  Tolerance 1e-13 relative to the largest entry (sums of m products)."""
+    import torch
+    from capital_amd import capi
+    h = capi.Handle(0)
+    torch.manual_seed(m + n)
+    ld = m + pad
+    A = torch.rand((n, ld), dtype=torch.float64, device="cuda") - 0.5           # column-major m x n, leading dimension ld
+    Q = torch.zeros((n, ld), dtype=torch.float64, device="cuda")
+    T = torch.triu(torch.rand((n, n), dtype=torch.float64, device="cuda") - 0.5)
+    Tcm = T.T.contiguous()                                                       # column-major storage of upper T
+    G = torch.zeros((n, n), dtype=torch.float64, device="cuda")
+    h.call("capi_dsyrk", 1, 1, n, m, 1.0, capi.ptr(A), ld, 0.0, capi.ptr(G), n)
+    h.call("capi_dtrmm_oop", 1, 1, 0, 0, m, n, 1.0, capi.ptr(Tcm), n, capi.ptr(A), ld, capi.ptr(Q), ld)
+    h.sync()
+    Am = A[:, :m].T
+    Gref = torch.triu(Am.T @ Am)
+    Gout = torch.triu(G.T)
+    Qref = Am @ T
+    Qout = Q[:, :m].T
+    assert (Gout - Gref).abs().max().item() <= 1e-13 * Gref.abs().max().item()
+    assert (Qout - Qref).abs().max().item() <= 1e-13 * Qref.abs().max().item()
+    assert torch.count_nonzero(Q[:, m:]).item() == 0                            # nothing written past row m
+    assert torch.count_nonzero(torch.tril(G.T, -1)).item() == 0                  # lower triangle of G untouched

@@ -115,9 +115,9 @@ def main():
     flops = n ** 3 / 3.0
     value = flops / (ms_per_step * 1e-3) / 1e12
 
-    # roofline of the dominant kernel: every launch of the TN MFMA tile kernel in the timed region, HIP events on its stream
+    # roofline of the dominant kernel: every launch of the 128-tile TN MFMA kernel in the timed region, HIP events on its stream
     launches, tot_ms, tot_fl, max_ms = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
-    L.capi_prof_collect(h, 3, C.byref(launches), C.byref(tot_ms), C.byref(tot_fl), C.byref(max_ms))
+    L.capi_prof_collect(h, 11, C.byref(launches), C.byref(tot_ms), C.byref(tot_fl), C.byref(max_ms))   # 8 + 3: the 128-tile TN kernel, one symbol
     achieved = tot_fl.value / (tot_ms.value * 1e-3) / 1e12 if tot_ms.value > 0 else 0.0
     allv = [C.c_int64(), C.c_double(), C.c_double()]
     L.capi_prof_collect(h, -1, C.byref(allv[0]), C.byref(allv[1]), C.byref(allv[2]), None)
@@ -134,7 +134,7 @@ def main():
                    "n": n, "grid": [prob.d, prob.d, prob.c], "base_case_order": stats["bc_dimension"], "residual": residual, "summa_chunks": chunks},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": None,
-                     "kernel": "dgemm_tile_kernel<true,true> (trailing update + R12 solve)",
+                     "kernel": "dgemm_tile_kernel<128,true,true> (trailing update + R12 solve, orders >= 4096)",
                      "launches_per_step": launches.value / max(args.steps, 1),
                      "avg_launch_ms": tot_ms.value / max(launches.value, 1), "max_launch_ms": max_ms.value,
                      "avg_flops_per_launch": tot_fl.value / max(launches.value, 1),

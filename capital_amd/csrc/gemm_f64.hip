@@ -1230,7 +1230,8 @@ int capi_prof_collect(capi_handle_t h, int variant, int64_t* launches, double* t
   *launches = 0; *total_ms = 0; *total_flops = 0;
   if (max_ms) *max_ms = 0;
   for (int i = 0; i < h->prof_n; ++i) {
-    if (variant >= 0 && (h->prof[i].variant & 3) != variant) continue;
+    // 0..3: operand orientations, any tile size;  8 + v: exactly variant v (bit 2 set = 64-tile kernel)
+    if (variant >= 8 ? h->prof[i].variant != variant - 8 : (variant >= 0 && (h->prof[i].variant & 3) != variant)) continue;
     float ms = 0;
     CAPI_HIP_CHECK(h, hipEventElapsedTime(&ms, h->prof[i].e0, h->prof[i].e1));
     *launches += 1; *total_ms += ms; *total_flops += h->prof[i].flops;

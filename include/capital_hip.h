@@ -168,7 +168,9 @@ int capi_event_wait(capi_handle_t h, int slot);     /* the currently selected st
 int capi_mfma_f64_peak(capi_handle_t h, int iters, double* tflops);
 /* HIP-event bracket around EVERY launch of the MFMA tile kernel on the handle's stream (roofline measurement):
  * enable, run the workload, collect = number of launches, summed duration and summed algorithmic flops of one
- * kernel variant (3 = both operands k-contiguous, the TN kernel of the trailing update; -1 = all variants). */
+ * kernel variant (0..3 = operand orientations at any tile size, 3 = both operands k-contiguous, the TN kernel of the
+ * trailing update; 8 + v = exactly variant v, where bit 2 of v marks the 64-tile kernel: 11 = the 128-tile TN kernel
+ * alone, i.e. one kernel symbol; -1 = all variants). */
 int capi_prof_enable(capi_handle_t h, int on);
 int capi_prof_collect(capi_handle_t h, int variant, int64_t* launches, double* total_ms, double* total_flops, double* max_ms);
 /* HIP-event timer on the handle's stream */

@@ -18,6 +18,12 @@
 //     second kernel reduces in a fixed order (bit-reproducible, no atomics);
 //   * workgroup ids are re-dealt so that the 64 tiles an XCD runs concurrently form a compact block
 //     of the output (8 XCDs x private 4 MiB L2).
+// Around it, in this file: dgemm_small_kernel (order <= 512: 32 x 32 tiles, K in 256-deep bursts -- the recursion's
+// latency-bound levels), gram_ts_kernel and trmm_right_ts_kernel (CholeskyQR2's tall-skinny Gram matrix and Q = A R^-1,
+// full-width workgroups that read the tall operand once), and launch_gemm, which picks between them with a makespan
+// model in CU-cycles.
+// Diagnostic environment switches (read once): CAPI_DEBUG_GEMM (print every choice), CAPI_FORCE_TS=64|128, CAPI_SMALL=0|1,
+// CAPI_NO_TS, CAPI_NO_SHARE, CAPI_NO_SKIP, CAPI_NO_ROTATE, CAPI_PEAK_BLOCKS_PER_CU.
 #include "capi_internal.h"
 #include <type_traits>
 
@@ -52,13 +58,11 @@ struct GemmArgs {
   int tri_unit;
   int a_vec, b_vec;   // 16-byte loads legal for A / B
   int splitk, k_per_split;
-  int k_interleave;   // split-K slices are interleaved panel by panel (slice z owns panels z, z+splitk, ...) instead of contiguous
   int k_rotate;       // split-K slice z starts its k-loop z/splitk of the way through its range and wraps around
   double* slab;       // split-K partial sums: slab[z*slab_stride + i + j*slab_ld]
   int64_t slab_ld, slab_stride;
   int tiles_m, tiles_n, ntiles;
   int ts;             // tile size chosen by the launcher
-  int stagger;        // cycles/64 by which odd-numbered co-resident workgroups delay their start (0 = off)
   int no_skip;        // diagnostics: never skip zero sub-tiles
   int share_ab;       // A and B are the same matrix in the same orientation (syrk): diagonal tiles stage ONE panel
 };
@@ -240,17 +244,6 @@ __global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel
   const int r16 = lane & 15, g = lane >> 4;
   const int wm = wave & 1, wn = wave >> 1;
 
-  // Two workgroups share a CU (one wave of each per SIMD) and run the same program at the same rate: started together
-  // they stay in lockstep, so their load/staging phases (no MFMA) coincide and the matrix pipe idles in both at once.
-  // The workgroup that got the odd threadgroup slot of its CU starts half a panel late; the offset then persists.
-  if ((p.stagger & 1023) > 0) {
-    unsigned hwid;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    if ((hwid >> 16) & 1) {
-      for (int i = 0; i < (p.stagger & 1023); i += 64) __builtin_amdgcn_s_sleep(64);
-    }
-  }
-
   // XCD-aware re-deal: consecutive pids share an XCD (dispatcher deals blockIdx round-robin over 8 XCDs)
   const int nblk = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, qq = nblk >> 3, rr = nblk & 7;
@@ -268,18 +261,10 @@ __global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel
   } else if (p.tri_side == CAPI_RIGHT) {
     if (p.tri_eff_upper) khi = min(p.K, j0 + BN); else klo = j0;
   }
-  // kstep: distance between the panels this workgroup multiplies.  Interleaved split-K (no triangular operand) makes
-  // the slices that are resident together read neighbouring rows of a tall operand: a few sequential DRAM streams and
-  // shared L2 lines instead of tiles x slices scattered ones.
-  int kstep = BK;
+  constexpr int kstep = BK;
   if (p.splitk > 1) {
-    if (p.k_interleave) {
-      klo = z * BK;
-      kstep = p.splitk * BK;
-    } else {
-      klo = max(klo, z * p.k_per_split);
-      khi = min(khi, (z + 1) * p.k_per_split);
-    }
+    klo = max(klo, z * p.k_per_split);
+    khi = min(khi, (z + 1) * p.k_per_split);
   }
   const int ntk = khi > klo ? (khi - klo + kstep - 1) / kstep : 0;
   const bool maskA = p.tri_side == CAPI_LEFT, maskB = p.tri_side == CAPI_RIGHT;
@@ -1040,11 +1025,9 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
   p.a_vec = (((uintptr_t)p.A & 15) == 0) && ((p.lda & 1) == 0);
   p.b_vec = (((uintptr_t)p.B & 15) == 0) && ((p.ldb & 1) == 0);
   p.no_skip = getenv("CAPI_NO_SKIP") ? 1 : 0;
-  p.stagger = getenv("CAPI_STAGGER") ? atoi(getenv("CAPI_STAGGER")) : 0;
   p.share_ab = (p.out_uplo >= 0 && p.A == p.B && p.lda == p.ldb && ak == bkc && !getenv("CAPI_NO_SHARE")) ? 1 : 0;
   p.splitk = 1;
   p.k_per_split = p.K;
-  p.k_interleave = 0;
   p.k_rotate = 0;
   p.slab = nullptr;
   p.slab_ld = p.slab_stride = 0;
@@ -1054,8 +1037,7 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
     if (sk > 1) {
       p.splitk = (int)sk;
       p.k_per_split = (int)kps;
-      p.k_interleave = (!tri && getenv("CAPI_INTERLEAVE")) ? 1 : 0;
-      p.k_rotate = (!tri && !p.k_interleave && !getenv("CAPI_NO_ROTATE")) ? 1 : 0;
+      p.k_rotate = (!tri && !getenv("CAPI_NO_ROTATE")) ? 1 : 0;
       p.slab_ld = p.M;
       p.slab_stride = (int64_t)p.M * p.N;
       void* ws;

@@ -1,7 +1,8 @@
 // comm_rccl.hip -- the reference's MPI collectives (C1-C10) as RCCL calls on the handle's HIP
 // stream.  RCCL is bound at run time with dlopen so that (a) single-GPU use never loads it and (b) inside a
 // torch.distributed process the SAME librccl.so.1 that torch already mapped is reused (one RCCL per process).
-// One process per GPU; communicators of size 1 short-circuit every call.
+// One process per GPU; communicators of size 1 short-circuit every call -- unless CAPI_RCCL_FORCE is set, which sends
+// even a 1-rank communicator through the real library (the only way to exercise these wrappers on a 1-GPU box).
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 #include "capi_internal.h"
@@ -97,7 +98,7 @@ int capi_comm_init_rank(capi_comm_t* out, capi_handle_t h, int nranks, const voi
   c->h = h;
   c->rank = rank;
   c->size = nranks;
-  if (nranks > 1) {
+  if (nranks > 1 || getenv("CAPI_RCCL_FORCE")) {
     CAPI_REQUIRE(h, id128, "unique id");
     int rc = rccl_bind(nullptr);
     if (rc != CAPI_OK) { snprintf(h->err, sizeof(h->err), "%s", g_rccl_err); delete c; return rc; }
@@ -114,7 +115,7 @@ int capi_comm_split(capi_comm_t parent, int color, int key, capi_comm_t* child) 
   if (!parent || !child) return CAPI_EINVAL;
   capi_comm_s* c = new capi_comm_s();
   c->h = parent->h;
-  if (parent->size == 1) {
+  if (!parent->comm) {
     c->rank = 0;
     c->size = 1;
   } else {
@@ -143,14 +144,14 @@ int capi_comm_destroy(capi_comm_t c) {
 
 int capi_bcast(capi_comm_t c, double* buf, int64_t count, int root) {
   if (!c || count < 0 || root < 0 || root >= c->size) return CAPI_EINVAL;
-  if (c->size == 1 || count == 0) return CAPI_OK;
+  if (!c->comm || count == 0) return CAPI_OK;
   NCCL_CHECK(c, g_rccl.Broadcast(buf, buf, (size_t)count, ncclDouble, root, c->comm, c->h->stream));
   return CAPI_OK;
 }
 
 int capi_allreduce_sum(capi_comm_t c, double* buf, int64_t count) {
   if (!c || count < 0) return CAPI_EINVAL;
-  if (c->size == 1 || count == 0) return CAPI_OK;
+  if (!c->comm || count == 0) return CAPI_OK;
   NCCL_CHECK(c, g_rccl.AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, c->comm, c->h->stream));
   return CAPI_OK;
 }
@@ -158,7 +159,7 @@ int capi_allreduce_sum(capi_comm_t c, double* buf, int64_t count) {
 int capi_reduce_sum(capi_comm_t c, const double* send, double* recv, int64_t count, int root) {
   if (!c || count < 0 || root < 0 || root >= c->size) return CAPI_EINVAL;
   if (count == 0) return CAPI_OK;
-  if (c->size == 1) {
+  if (!c->comm) {
     if (send != recv) CAPI_HIP_CHECK(c->h, hipMemcpyAsync(recv, send, sizeof(double) * count, hipMemcpyDeviceToDevice, c->h->stream));
     return CAPI_OK;
   }
@@ -169,7 +170,7 @@ int capi_reduce_sum(capi_comm_t c, const double* send, double* recv, int64_t cou
 int capi_allgather(capi_comm_t c, const double* send, double* recv, int64_t count) {
   if (!c || count < 0) return CAPI_EINVAL;
   if (count == 0) return CAPI_OK;
-  if (c->size == 1) {
+  if (!c->comm) {
     if (send != recv) CAPI_HIP_CHECK(c->h, hipMemcpyAsync(recv, send, sizeof(double) * count, hipMemcpyDeviceToDevice, c->h->stream));
     return CAPI_OK;
   }
@@ -179,7 +180,7 @@ int capi_allgather(capi_comm_t c, const double* send, double* recv, int64_t coun
 
 int capi_sendrecv_replace(capi_comm_t c, double* buf, int64_t count, int peer, double* staging) {
   if (!c || count < 0 || peer < 0 || peer >= c->size) return CAPI_EINVAL;
-  if (count == 0 || peer == c->rank) return CAPI_OK;
+  if (count == 0 || (peer == c->rank && !(c->comm && c->size == 1))) return CAPI_OK;   // (forced 1-rank communicator: a real self send/recv)
   if (!staging) return CAPI_EINVAL;
   NCCL_CHECK(c, g_rccl.GroupStart());
   NCCL_CHECK(c, g_rccl.Send(buf, (size_t)count, ncclDouble, peer, c->comm, c->h->stream));

@@ -62,6 +62,7 @@ struct GemmArgs {
   double* slab;       // split-K partial sums: slab[z*slab_stride + i + j*slab_ld]
   int64_t slab_ld, slab_stride;
   int tiles_m, tiles_n, ntiles;
+  int tail_base, tail_tm, tail_tn;   // > 0: this 64-tile launch covers the four quarters of the 128-tiles [tail_base, ...) of a tail_tm x tail_tn tiling
   int ts;             // tile size chosen by the launcher
   int no_skip;        // diagnostics: never skip zero sub-tiles
   int share_ab;       // A and B are the same matrix in the same orientation (syrk): diagonal tiles stage ONE panel
@@ -198,10 +199,9 @@ __device__ __forceinline__ void mfma_step(d4_t (&acc)[SUB][SUB], const d2_t (&af
   }
 }
 
-__device__ __forceinline__ void tile_of(const GemmArgs& p, int t, int& ti, int& tj) {
-  if (p.out_uplo < 0) {
+__device__ __forceinline__ void tile_of_dims(int out_uplo, int nm, int nn, int t, int& ti, int& tj) {
+  if (out_uplo < 0) {
     // bands of GROUP_M tile-rows (all tile-columns) are dealt to XCDs in order
-    const int nm = p.tiles_m, nn = p.tiles_n;
     const int in_group = GROUP_M * nn;
     const int group = t / in_group;
     const int first_m = group * GROUP_M;
@@ -215,7 +215,19 @@ __device__ __forceinline__ void tile_of(const GemmArgs& p, int t, int& ti, int& 
     while ((int64_t)hi * (hi + 1) / 2 > t) --hi;
     while ((int64_t)(hi + 1) * (hi + 2) / 2 <= t) ++hi;
     const int lo = t - (int)((int64_t)hi * (hi + 1) / 2);
-    if (p.out_uplo == CAPI_UPPER) { ti = lo; tj = hi; } else { ti = hi; tj = lo; }
+    if (out_uplo == CAPI_UPPER) { ti = lo; tj = hi; } else { ti = hi; tj = lo; }
+  }
+}
+
+__device__ __forceinline__ void tile_of(const GemmArgs& p, int t, int& ti, int& tj) {
+  if (p.tail_base > 0) {
+    // the last, partially filled round of a 128-tiling is re-cut into 64-tiles: quarter t & 3 of 128-tile tail_base + t / 4
+    int ti128, tj128;
+    tile_of_dims(p.out_uplo, p.tail_tm, p.tail_tn, p.tail_base + (t >> 2), ti128, tj128);
+    ti = 2 * ti128 + (t & 1);
+    tj = 2 * tj128 + ((t >> 1) & 1);
+  } else {
+    tile_of_dims(p.out_uplo, p.tiles_m, p.tiles_n, t, ti, tj);
   }
 }
 
@@ -252,6 +264,11 @@ __global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel
   int ti, tj;
   if (p.tri_side >= 0 && p.splitk == 1) { z = 0; trmm_tile_of(p, bid, ti, tj); }
   else tile_of(p, pid - z * p.ntiles, ti, tj);
+  if (p.tail_base > 0) {                      // quarters outside the matrix or wholly in the unwanted triangle (uniform per workgroup)
+    if (ti >= p.tiles_m || tj >= p.tiles_n) return;
+    if (p.out_uplo == CAPI_UPPER && ti > tj) return;
+    if (p.out_uplo == CAPI_LOWER && tj > ti) return;
+  }
   const int i0 = ti * BM, j0 = tj * BN;
 
   // k-range of this tile
@@ -1046,6 +1063,18 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
       p.slab = (double*)ws;
     }
   }
+  // A 128-tiling fills the chip in rounds of 2 x CUs workgroups; the last round is usually partial and its lone
+  // workgroups run at ~0.6 of the paired rate (8256 tiles = 16 rounds + 64: those 64 cost almost another round).  The
+  // tail is re-cut into 64-tiles (4x the workgroups, a quarter of the length) and launched right behind the full rounds.
+  int tail128 = 0;
+  if (p.ts == 128 && p.splitk == 1 && !tri && !getenv("CAPI_NO_TAIL")) {
+    const int per_round = 2 * h->num_cu;
+    const int rem = p.ntiles % per_round;
+    if (p.ntiles >= 2 * per_round && rem > 0 && rem <= (3 * per_round) / 4) tail128 = rem;
+  }
+  const int ntiles_all = p.ntiles;
+  p.tail_base = 0; p.tail_tm = p.tail_tn = 0;
+  p.ntiles -= tail128;
   gemm_kernel_t k = p.ts == 128 ? pick_kernel<128>(ak, bkc) : pick_kernel<64>(ak, bkc);
   const size_t lds_bytes = sizeof(double) * 2 * (p.ts == 128 ? tile_cfg<128>::STAGE_LDS : tile_cfg<64>::STAGE_LDS);
   const int64_t nblk = (int64_t)p.ntiles * p.splitk;
@@ -1065,12 +1094,24 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
     // algorithmic flops of this launch: gemm 2MNK, triangular output N(N+1)K, trmm M^2 N / M N^2
     rec->flops = p.out_uplo >= 0 ? (double)p.N * ((double)p.N + 1.0) * (double)p.K
                  : (p.tri_side >= 0 ? (double)p.M * (double)p.N * (double)p.K : 2.0 * (double)p.M * (double)p.N * (double)p.K);
+    rec->flops *= (double)p.ntiles / (double)ntiles_all;           // (the tail launch below is not part of this record)
     rec->variant = (ak ? 2 : 0) + (bkc ? 1 : 0) + (p.ts == 128 ? 0 : 4);
     CAPI_HIP_CHECK(h, hipEventRecord(rec->e0, s));
   }
   hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(NTHREADS), lds_bytes, s, p);
   CAPI_HIP_CHECK(h, hipGetLastError());
   if (rec) CAPI_HIP_CHECK(h, hipEventRecord(rec->e1, s));
+  if (tail128 > 0) {
+    GemmArgs q = p;
+    q.ts = 64;
+    q.tail_base = p.ntiles;                 // first 128-tile of the tail (p.ntiles > 0 here)
+    q.tail_tm = p.tiles_m; q.tail_tn = p.tiles_n;
+    q.tiles_m = (int)cdiv(p.M, 64); q.tiles_n = (int)cdiv(p.N, 64);
+    q.ntiles = 4 * tail128;
+    hipLaunchKernelGGL(pick_kernel<64>(ak, bkc), dim3((unsigned)q.ntiles), dim3(NTHREADS),
+                       sizeof(double) * 2 * tile_cfg<64>::STAGE_LDS, s, q);
+    CAPI_HIP_CHECK(h, hipGetLastError());
+  }
   if (p.splitk > 1) {
     dim3 grid((unsigned)cdiv(p.M, 256), (unsigned)(p.N < 65535 ? p.N : 65535));
     hipLaunchKernelGGL(splitk_reduce_kernel, grid, dim3(256), 0, s, p.slab, p.slab_ld, p.slab_stride, p.splitk, p.C, p.ldc,

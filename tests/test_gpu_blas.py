@@ -195,3 +195,30 @@ def test_tall_skinny_gram_and_right_trmm(m, n, pad):
     assert (Qout - Qref).abs().max().item() <= 1e-13 * Qref.abs().max().item()
     assert torch.count_nonzero(Q[:, m:]).item() == 0                            # nothing written past row m
     assert torch.count_nonzero(torch.tril(G.T, -1)).item() == 0                  # lower triangle of G untouched
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,k", [(5000, 300), (6016, 200)])
+def test_partial_last_round_is_recut_into_64_tiles(n, k):
+    """Orders whose 128-tiling leaves a partial last round (1600 = 3 x 512 + 64 tiles for gemm 5000, 1128 = 2 x 512 + 104
+    for the triangle of 6016): the tail tiles are launched as 64-tiles; results must not change (gemm and triangular
+    output, 1e-13 relative)."""
+    import torch
+    from capital_amd import capi
+    h = capi.Handle(0)
+    torch.manual_seed(n)
+    A = torch.rand((n, k), dtype=torch.float64, device="cuda") - 0.5     # column-major k x n  (A^T is n x k)
+    B = torch.rand((n, k), dtype=torch.float64, device="cuda") - 0.5
+    C0 = torch.rand((n, n), dtype=torch.float64, device="cuda")
+    C1 = C0.clone()
+    h.call("capi_dgemm", 1, 0, n, n, k, -1.0, capi.ptr(A), k, capi.ptr(B), k, 1.0, capi.ptr(C1), n)     # C -= A^T B
+    h.sync()
+    ref = C0 - (B @ A.T)             # logical C = C0 - At*Bm with At = A (n x k rows), column-major view: C1 tensor holds C^T
+    assert (C1 - ref).abs().max().item() <= 1e-13 * ref.abs().max().item()
+    C2 = C0.clone()
+    h.call("capi_dgemmt", 1, 1, 0, n, k, -1.0, capi.ptr(A), k, capi.ptr(A), k, 1.0, capi.ptr(C2), n)    # upper of C -= A^T A
+    h.sync()
+    full = C0 - (A @ A.T)
+    # column-major upper triangle == lower triangle of the row-major tensor
+    assert (torch.tril(C2) - torch.tril(full)).abs().max().item() <= 1e-13 * full.abs().max().item()
+    assert torch.equal(torch.triu(C2, 1), torch.triu(C0, 1))             # the other triangle is untouched

@@ -57,6 +57,8 @@ _SIGS = {
     "capi_timer_start": [],
     "capi_timer_stop_ms": [C.POINTER(C.c_float)],
     "capi_sync": [],
+    "capi_dgeqrf": [_i64, _i64, _vp, _i64, _vp],
+    "capi_dorgqr": [_i64, _i64, _i64, _vp, _i64, _vp],
     "capi_reserve_workspace": [C.c_size_t],
     "capi_memset_async": [_vp, _int, C.c_size_t],
     "capi_memcpy_h2d": [_vp, _vp, C.c_size_t],

@@ -1,0 +1,256 @@
+// qr_f64.hip -- Householder QR for gfx950: capi_dgeqrf / capi_dorgqr behind lapack::engine::_geqrf / _orgqr
+// (reference src/lapack/interface.hpp:60-88, LAPACKE_dgeqrf / LAPACKE_dorgqr; the reference has the engine slots but no
+// caller -- CholeskyQR2 is its QR -- so this is the numerically robust fallback of SURVEY.md 8f-2, not a hot path).
+//
+// Blocked right-looking with compact-WY block reflectors of width 32:
+//   panel      dgeqr2 column by column, five small launches per column: sum of squares (fixed partial slots, reduced in
+//              a fixed order -> bit-reproducible), reflector (dlarfg: beta = -sign(alpha) ||x||, tau = (beta-alpha)/beta,
+//              v = x / (alpha - beta)), v^T A over the rest of the panel, its reduction, and the rank-1 update;
+//   T          from G = V^T V (MFMA tile kernel, split-K over the rows) by the dlarft recurrence in one wave;
+//   trailing   A2 -= V (T^T (V^T A2)) as three products on the tile kernel.
+// dorgqr applies the block reflectors, last panel first, to [I; 0] in workspace and copies the result over A.
+// HBM-bound per column (the panel is re-read twice per column); dlarfg's rescaling loop for subnormal norms is omitted.
+#include "capi_internal.h"
+
+namespace {
+
+constexpr int QNB = 32;      // block reflector width
+constexpr int QPART = 512;   // partial-sum slots of the column reductions
+
+__device__ __forceinline__ double block_sum(double v, double* red) {   // sum over a 256-thread workgroup, fixed order
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// part[b] = sum of x_r^2 over this workgroup's rows of x (len entries)
+__global__ void col_sumsq_kernel(const double* __restrict__ x, int64_t len, double* __restrict__ part) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < len; r += (int64_t)gridDim.x * 256) s += x[r] * x[r];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+// dlarfg on column j: a = &A[j][j], x = a + 1 (len entries below the diagonal)
+__global__ void make_reflector_kernel(double* __restrict__ a, int64_t len, const double* __restrict__ part, int npart,
+                                      double* __restrict__ tau) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < npart; i += 256) s += part[i];
+  const double xnorm2 = block_sum(s, red);
+  const double alpha = a[0];
+  if (xnorm2 == 0.0) {                                       // H = I
+    if (blockIdx.x == 0 && threadIdx.x == 0) *tau = 0.0;
+    return;
+  }
+  const double nrm = sqrt(alpha * alpha + xnorm2);
+  const double beta = alpha >= 0.0 ? -nrm : nrm;
+  const double scal = 1.0 / (alpha - beta);
+  __syncthreads();                                           // every thread has read a[0] before it is overwritten
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < len; r += (int64_t)gridDim.x * 256) a[1 + r] *= scal;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { *tau = (beta - alpha) / beta; }
+}
+// (the diagonal entry is set to beta by a separate one-thread kernel AFTER every workgroup has read alpha)
+__global__ void set_beta_kernel(double* __restrict__ a, const double* __restrict__ part, int npart) {
+  double s = 0.0;
+  for (int i = 0; i < npart; ++i) s += part[i];
+  if (s == 0.0) return;
+  const double alpha = a[0], nrm = sqrt(alpha * alpha + s);
+  a[0] = alpha >= 0.0 ? -nrm : nrm;
+}
+
+// part2[b][c] = sum over this workgroup's rows of v_r * A[r][c+1], c = 0..nc-1; v_0 = 1, v_r = a[r] (column j below the diagonal)
+__global__ void panel_dot_kernel(const double* __restrict__ a, int64_t lda, int64_t rows, int nc, double* __restrict__ part2) {
+  __shared__ double red[4];
+  double acc[QNB - 1];
+#pragma unroll
+  for (int c = 0; c < QNB - 1; ++c) acc[c] = 0.0;
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (int64_t)gridDim.x * 256) {
+    const double v = r == 0 ? 1.0 : a[r];
+#pragma unroll
+    for (int c = 0; c < QNB - 1; ++c)
+      if (c < nc) acc[c] += v * a[r + (int64_t)(c + 1) * lda];
+  }
+#pragma unroll
+  for (int c = 0; c < QNB - 1; ++c) {
+    if (c < nc) {
+      const double s = block_sum(acc[c], red);
+      if (threadIdx.x == 0) part2[(int64_t)blockIdx.x * QNB + c] = s;
+    }
+  }
+}
+
+// w[c] = tau * sum_b part2[b][c]
+__global__ void reduce_w_kernel(const double* __restrict__ part2, int npart, int nc, const double* __restrict__ tau, double* __restrict__ w) {
+  const int c = threadIdx.x;
+  if (c >= nc) return;
+  double s = 0.0;
+  for (int b = 0; b < npart; ++b) s += part2[(int64_t)b * QNB + c];
+  w[c] = (*tau) * s;
+}
+
+// A[r][c+1] -= v_r * w[c]
+__global__ void panel_apply_kernel(double* __restrict__ a, int64_t lda, int64_t rows, int nc, const double* __restrict__ w) {
+  double wl[QNB - 1];
+#pragma unroll
+  for (int c = 0; c < QNB - 1; ++c) wl[c] = c < nc ? w[c] : 0.0;
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (int64_t)gridDim.x * 256) {
+    const double v = r == 0 ? 1.0 : a[r];
+#pragma unroll
+    for (int c = 0; c < QNB - 1; ++c)
+      if (c < nc) a[r + (int64_t)(c + 1) * lda] -= v * wl[c];
+  }
+}
+
+// Vw (rows x nb, ld rows) <- the panel's reflectors: unit diagonal, zeros above, A's entries below
+__global__ void form_v_kernel(const double* __restrict__ a, int64_t lda, int64_t rows, int nb, double* __restrict__ vw) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  for (int c = blockIdx.y; c < nb; c += gridDim.y) vw[r + (int64_t)c * rows] = r < c ? 0.0 : (r == c ? 1.0 : a[r + (int64_t)c * lda]);
+}
+
+// dlarft (forward, columnwise): T upper triangular nb x nb (full storage, zeros below) from G = V^T V and tau
+__global__ void larft_kernel(const double* __restrict__ G, const double* __restrict__ tau, int nb, double* __restrict__ T) {
+  __shared__ double t[QNB][QNB + 1];
+  const int i0 = threadIdx.x;
+  for (int c = 0; c < nb; ++c) if (i0 < nb) t[i0][c] = 0.0;
+  __syncthreads();
+  for (int i = 0; i < nb; ++i) {
+    const double ti = tau[i];
+    // T(0:i, i) = -tau_i * T(0:i, 0:i) * G(0:i, i)
+    double s = 0.0;
+    if (i0 < i)
+      for (int l = i0; l < i; ++l) s += t[i0][l] * G[l + (int64_t)i * nb];
+    __syncthreads();
+    if (i0 < i) t[i0][i] = -ti * s;
+    if (i0 == i) t[i][i] = ti;
+    __syncthreads();
+  }
+  for (int c = 0; c < nb; ++c) if (i0 < nb) T[i0 + (int64_t)c * nb] = t[i0][c];
+}
+
+__global__ void identity_kernel(double* __restrict__ Q, int64_t m, int64_t n) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= m) return;
+  for (int64_t c = blockIdx.y; c < n; c += gridDim.y) Q[r + c * m] = r == c ? 1.0 : 0.0;
+}
+
+#define RC(x) do { int rc__ = (x); if (rc__ != CAPI_OK) return rc__; } while (0)
+
+int nslots(int64_t rows) {
+  int64_t b = cdiv(rows, 2048);
+  return (int)(b < 1 ? 1 : (b > QPART ? QPART : b));
+}
+
+struct qr_ws {
+  double *Vw, *W, *W2, *G, *T, *part, *wv, *Q;
+};
+
+int qr_workspace(capi_handle_t h, int64_t m, int64_t n, bool with_q, qr_ws& w) {
+  const size_t nV = (size_t)m * QNB, nW = (size_t)QNB * (size_t)n, nQ = with_q ? (size_t)m * (size_t)n : 0;
+  const size_t total = nV + 2 * nW + 2 * QNB * QNB + (size_t)QPART * QNB + QNB + nQ + 64;
+  void* p;
+  RC(capi_ws2_get(h, sizeof(double) * total, &p));
+  double* d = (double*)p;
+  w.Vw = d; d += nV;
+  w.W = d; d += nW;
+  w.W2 = d; d += nW;
+  w.G = d; d += QNB * QNB;
+  w.T = d; d += QNB * QNB;
+  w.part = d; d += (size_t)QPART * QNB;
+  w.wv = d; d += QNB;
+  w.Q = d;
+  return CAPI_OK;
+}
+
+// Vw, G = Vw^T Vw and T of the panel at (j0, j0) of width nb
+int block_reflector(capi_handle_t h, const double* Apanel, int64_t lda, int64_t rows, int nb, const double* tau, qr_ws& w) {
+  hipStream_t s = h->stream;
+  hipLaunchKernelGGL(form_v_kernel, dim3((unsigned)cdiv(rows, 256), (unsigned)nb), dim3(256), 0, s, Apanel, lda, rows, nb, w.Vw);
+  CAPI_HIP_CHECK(h, hipGetLastError());
+  RC(capi_dgemm(h, CAPI_TRANS, CAPI_NOTRANS, nb, nb, rows, 1.0, w.Vw, rows, w.Vw, rows, 0.0, w.G, nb));
+  hipLaunchKernelGGL(larft_kernel, dim3(1), dim3(64), 0, s, w.G, tau, nb, w.T);
+  CAPI_HIP_CHECK(h, hipGetLastError());
+  return CAPI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int capi_dgeqrf(capi_handle_t h, int64_t m, int64_t n, double* A, int64_t lda, double* tau) {
+  CAPI_REQUIRE(h, h, "null handle");
+  CAPI_REQUIRE(h, m >= 0 && n >= 0 && m < (1LL << 31) && n < (1LL << 31), "dims");
+  if (m == 0 || n == 0) return CAPI_OK;
+  CAPI_REQUIRE(h, A && tau && lda >= m, "operands");
+  const int64_t k = m < n ? m : n;
+  qr_ws w;
+  RC(qr_workspace(h, m, n, false, w));
+  hipStream_t s = h->stream;
+  for (int64_t j0 = 0; j0 < k; j0 += QNB) {
+    const int nb = (int)(k - j0 < QNB ? k - j0 : QNB);
+    // panel: columns j0 .. j0+nb-1, one reflector at a time
+    for (int c = 0; c < nb; ++c) {
+      const int64_t j = j0 + c, rows = m - j, len = rows - 1;
+      double* a = A + j + j * lda;
+      const int np = nslots(len > 0 ? len : 1);
+      if (len > 0) {
+        hipLaunchKernelGGL(col_sumsq_kernel, dim3(np), dim3(256), 0, s, a + 1, len, w.part);
+        hipLaunchKernelGGL(make_reflector_kernel, dim3(np), dim3(256), 0, s, a, len, w.part, np, tau + j);
+        hipLaunchKernelGGL(set_beta_kernel, dim3(1), dim3(1), 0, s, a, w.part, np);
+      } else {
+        CAPI_HIP_CHECK(h, hipMemsetAsync(tau + j, 0, sizeof(double), s));   // last row: H = I
+      }
+      const int nc = nb - 1 - c;                              // columns of the panel right of j
+      if (nc > 0) {
+        const int np2 = nslots(rows);
+        hipLaunchKernelGGL(panel_dot_kernel, dim3(np2), dim3(256), 0, s, a, lda, rows, nc, w.part);
+        hipLaunchKernelGGL(reduce_w_kernel, dim3(1), dim3(QNB), 0, s, w.part, np2, nc, tau + j, w.wv);
+        hipLaunchKernelGGL(panel_apply_kernel, dim3(np2), dim3(256), 0, s, a, lda, rows, nc, w.wv);
+      }
+      CAPI_HIP_CHECK(h, hipGetLastError());
+    }
+    // trailing block A2 = A[j0:m, j0+nb:n]:  A2 <- (I - V T^T V^T) A2
+    const int64_t n2 = n - j0 - nb, rows = m - j0;
+    if (n2 > 0) {
+      double* Ap = A + j0 + j0 * lda;
+      double* A2 = A + j0 + (j0 + nb) * lda;
+      RC(block_reflector(h, Ap, lda, rows, nb, tau + j0, w));
+      RC(capi_dgemm(h, CAPI_TRANS, CAPI_NOTRANS, nb, n2, rows, 1.0, w.Vw, rows, A2, lda, 0.0, w.W, nb));
+      RC(capi_dgemm(h, CAPI_TRANS, CAPI_NOTRANS, nb, n2, nb, 1.0, w.T, nb, w.W, nb, 0.0, w.W2, nb));
+      RC(capi_dgemm(h, CAPI_NOTRANS, CAPI_NOTRANS, rows, n2, nb, -1.0, w.Vw, rows, w.W2, nb, 1.0, A2, lda));
+    }
+  }
+  return CAPI_OK;
+}
+
+int capi_dorgqr(capi_handle_t h, int64_t m, int64_t n, int64_t k, double* A, int64_t lda, const double* tau) {
+  CAPI_REQUIRE(h, h, "null handle");
+  CAPI_REQUIRE(h, m >= 0 && n >= 0 && n <= m && k >= 0 && k <= n && m < (1LL << 31), "dims (m >= n >= k >= 0)");
+  if (m == 0 || n == 0) return CAPI_OK;
+  CAPI_REQUIRE(h, A && lda >= m && (tau || k == 0), "operands");
+  qr_ws w;
+  RC(qr_workspace(h, m, n, true, w));
+  hipStream_t s = h->stream;
+  hipLaunchKernelGGL(identity_kernel, dim3((unsigned)cdiv(m, 256), (unsigned)(n < 65535 ? n : 65535)), dim3(256), 0, s, w.Q, m, n);
+  CAPI_HIP_CHECK(h, hipGetLastError());
+  // Q = H_1 ... H_k [I; 0]: block reflectors applied last panel first; panel p only touches Q[j0:m, j0:n]
+  const int64_t last = k > 0 ? ((k - 1) / QNB) * QNB : -1;
+  for (int64_t j0 = last; j0 >= 0; j0 -= QNB) {
+    const int nb = (int)(k - j0 < QNB ? k - j0 : QNB);
+    const int64_t rows = m - j0, nq = n - j0;
+    RC(block_reflector(h, A + j0 + j0 * lda, lda, rows, nb, tau + j0, w));
+    double* Qs = w.Q + j0 + j0 * m;
+    RC(capi_dgemm(h, CAPI_TRANS, CAPI_NOTRANS, nb, nq, rows, 1.0, w.Vw, rows, Qs, m, 0.0, w.W, nb));
+    RC(capi_dgemm(h, CAPI_NOTRANS, CAPI_NOTRANS, nb, nq, nb, 1.0, w.T, nb, w.W, nb, 0.0, w.W2, nb));
+    RC(capi_dgemm(h, CAPI_NOTRANS, CAPI_NOTRANS, rows, nq, nb, -1.0, w.Vw, rows, w.W2, nb, 1.0, Qs, m));
+  }
+  return capi_dlacpy(h, 0, m, n, w.Q, m, A, lda);
+}
+
+}  // extern "C"

@@ -49,11 +49,12 @@ public:
   static void _potrf(T* A, int n, int lda, const ArgPack_potrf& p);
   template <typename T>
   static void _trtri(T* A, int n, int lda, const ArgPack_trtri& p);
-  // declared by the reference (lapack/interface.h:55-59) with no caller anywhere; not served.
+  // declared by the reference (lapack/interface.h:55-59, interface.hpp:60-88) with no caller anywhere;
+  // served by the Householder path of csrc/qr_f64.hip.  A and tau are DEVICE pointers.
   template <typename T>
-  static void _geqrf(T*, T*, int, int, int, const ArgPack_geqrf&) { throw std::logic_error("lapack::engine::_geqrf has no caller in the reference and no device kernel yet"); }
+  static void _geqrf(T* A, T* tau, int m, int n, int lda, const ArgPack_geqrf& p);
   template <typename T>
-  static void _orgqr(T*, T*, int, int, int, int, const ArgPack_orgqr&) { throw std::logic_error("lapack::engine::_orgqr has no caller in the reference and no device kernel yet"); }
+  static void _orgqr(T* A, T* tau, int m, int n, int k, int lda, const ArgPack_orgqr& p);
   // synchronises; 0 or the 1-based index of the first non-positive pivot since the last reset
   static int info() { int v = 0; CAPITAL_CHECK(capi_get_info(capital::handle(), &v)); return v; }
   static void reset_info() { CAPITAL_CHECK(capi_reset_info(capital::handle())); }
@@ -68,6 +69,17 @@ template <>
 inline void engine::_trtri(double* A, int n, int lda, const ArgPack_trtri& p) {
   if (p.order != Order::AlapackColumnMajor) throw std::invalid_argument("lapack::engine: only AlapackColumnMajor is served");
   CAPITAL_CHECK(capi_dtrtri(capital::handle(), (int)p.uplo, (int)p.diag, n, A, lda));
+}
+
+template <>
+inline void engine::_geqrf(double* A, double* tau, int m, int n, int lda, const ArgPack_geqrf& p) {
+  if (p.order != Order::AlapackColumnMajor) throw std::invalid_argument("lapack::engine: only AlapackColumnMajor is served");
+  CAPITAL_CHECK(capi_dgeqrf(capital::handle(), m, n, A, lda, tau));
+}
+template <>
+inline void engine::_orgqr(double* A, double* tau, int m, int n, int k, int lda, const ArgPack_orgqr& p) {
+  if (p.order != Order::AlapackColumnMajor) throw std::invalid_argument("lapack::engine: only AlapackColumnMajor is served");
+  CAPITAL_CHECK(capi_dorgqr(capital::handle(), m, n, k, A, lda, tau));
 }
 
 }  // namespace lapack

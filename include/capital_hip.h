@@ -98,6 +98,12 @@ int capi_dtrtri(capi_handle_t h, int uplo, int diag, int64_t n, double* A, int64
  * Rinv <- R^-1 (upper); strictly-lower parts of both outputs are zeroed (cyclic_to_local, util.hpp:131-164). */
 int capi_dpotrf_trtri(capi_handle_t h, int64_t n, double* A, int64_t lda, double* Rinv, int64_t ldi);
 int capi_get_info(capi_handle_t h, int* info);
+/* LAPACKE_dgeqrf / LAPACKE_dorgqr behind lapack::engine::_geqrf / _orgqr (lapack/interface.hpp:60-88; the reference has
+ * the slots but no caller -- CholeskyQR2 is its QR).  Householder QR, LAPACK storage: R in the upper triangle, the
+ * reflectors v_j (unit first entry implied) below it, tau[min(m,n)] on the DEVICE.  capi_dorgqr overwrites A (m x n,
+ * m >= n >= k) with the first n columns of Q = H_1 ... H_k.  Blocked (compact WY, width 32) on the MFMA tile kernel. */
+int capi_dgeqrf(capi_handle_t h, int64_t m, int64_t n, double* A, int64_t lda, double* tau);
+int capi_dorgqr(capi_handle_t h, int64_t m, int64_t n, int64_t k, double* A, int64_t lda, const double* tau);
 int capi_reset_info(capi_handle_t h);
 
 /* ---- data movement: replaces serialize<> (src/matrix/serialize.hpp:12-150), the pack/unpack and

@@ -47,6 +47,10 @@ def lib():
         L.orc_dpotrf.restype = _int
         L.orc_dtrtri.argtypes = [_int, _int, _i64, _dp, _i64]
         L.orc_dtrtri.restype = _int
+        L.orc_dgeqrf.argtypes = [_i64, _i64, _dp, _i64, _dp]
+        L.orc_dgeqrf.restype = _int
+        L.orc_dorgqr.argtypes = [_i64, _i64, _i64, _dp, _i64, _dp]
+        L.orc_dorgqr.restype = _int
         for nm in ("orc_distribute_symmetric",):
             getattr(L, nm).argtypes = [_dp] + [_i64] * 9 + [_int]
         L.orc_distribute_random.argtypes = [_dp] + [_i64] * 9
@@ -134,6 +138,22 @@ def dpotrf(uplo, A, n=None):
 def dtrtri(uplo, diag, A, n=None):
     n = A.shape[0] if n is None else n
     return lib().orc_dtrtri(uplo, diag, n, _p(A), A.shape[0])
+
+
+def dgeqrf(A):
+    """In place on a Fortran-ordered (m, n) array: R above, reflectors below the diagonal; returns tau (min(m, n))."""
+    m, n = A.shape
+    tau = np.zeros(min(m, n))
+    lib().orc_dgeqrf(m, n, _p(A), A.shape[0], _p(tau))
+    return tau
+
+
+def dorgqr(A, tau, k=None):
+    """In place: the first n columns of Q = H_1 ... H_k from dgeqrf's output."""
+    m, n = A.shape
+    rc = lib().orc_dorgqr(m, n, len(tau) if k is None else k, _p(A), A.shape[0], _p(tau))
+    assert rc == 0
+    return A
 
 
 # ---- generators -----------------------------------------------------------------------------

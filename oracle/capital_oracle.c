@@ -395,6 +395,53 @@ int orc_dtrtri(int uplo, int diag, int64_t n, double* A, int64_t lda) {
   return 0;
 }
 
+/* Householder QR, unblocked LAPACK reference algorithms (dgeqr2 / dorg2r with dlarfg, dlarf): what LAPACKE_dgeqrf and
+ * LAPACKE_dorgqr (src/lapack/interface.hpp:60-88) compute up to blocking.  dlarfg's rescaling loop for subnormal
+ * norms is omitted, as in the HIP path. */
+int orc_dgeqrf(int64_t m, int64_t n, double* A, int64_t lda, double* tau) {
+  const int64_t k = MIN(m, n);
+  for (int64_t j = 0; j < k; ++j) {
+    double* a = A + j + j * lda;
+    double ss = 0.0;
+    for (int64_t r = 1; r < m - j; ++r) ss += a[r] * a[r];
+    if (ss == 0.0) { tau[j] = 0.0; continue; }
+    const double alpha = a[0], nrm = sqrt(alpha * alpha + ss), beta = alpha >= 0.0 ? -nrm : nrm;
+    const double scal = 1.0 / (alpha - beta);
+    for (int64_t r = 1; r < m - j; ++r) a[r] *= scal;
+    tau[j] = (beta - alpha) / beta;
+    a[0] = beta;
+    for (int64_t c = j + 1; c < n; ++c) {                 /* apply H_j to the columns on the right */
+      double* b = A + j + c * lda;
+      double w = b[0];
+      for (int64_t r = 1; r < m - j; ++r) w += a[r] * b[r];
+      w *= tau[j];
+      b[0] -= w;
+      for (int64_t r = 1; r < m - j; ++r) b[r] -= a[r] * w;
+    }
+  }
+  return 0;
+}
+
+int orc_dorgqr(int64_t m, int64_t n, int64_t k, double* A, int64_t lda, const double* tau) {
+  if (n > m || k > n) return -1;
+  double* Q = (double*)calloc((size_t)m * (size_t)n, sizeof(double));
+  for (int64_t c = 0; c < n; ++c) Q[c + c * m] = 1.0;
+  for (int64_t j = k - 1; j >= 0; --j) {                  /* Q <- H_j Q, v_j = [1; A[j+1:m, j]] */
+    const double* a = A + j + j * lda;
+    for (int64_t c = 0; c < n; ++c) {
+      double* q = Q + j + c * m;
+      double w = q[0];
+      for (int64_t r = 1; r < m - j; ++r) w += a[r] * q[r];
+      w *= tau[j];
+      q[0] -= w;
+      for (int64_t r = 1; r < m - j; ++r) q[r] -= a[r] * w;
+    }
+  }
+  for (int64_t c = 0; c < n; ++c) memcpy(A + c * lda, Q + c * m, sizeof(double) * (size_t)m);
+  free(Q);
+  return 0;
+}
+
 /* ------------------------------------------------------------------------------------------
  * Generators  (src/matrix/structure.hpp:36-129).  Restated loop-for-loop, including the
  * padding rule (a trailing local row/column of zeros when the grid does not divide the

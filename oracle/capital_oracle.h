@@ -57,6 +57,9 @@ void orc_dsyrk(int uplo, int trans, int64_t n, int64_t k, double alpha,
 int  orc_dpotrf(int uplo, int64_t n, double* A, int64_t lda);
 /* K9: LAPACKE_dtrtri, src/lapack/interface.hpp:54.  Returns LAPACK info. */
 int  orc_dtrtri(int uplo, int diag, int64_t n, double* A, int64_t lda);
+/* LAPACKE_dgeqrf / LAPACKE_dorgqr (lapack/interface.hpp:60-88): unblocked dgeqr2 / dorg2r */
+int  orc_dgeqrf(int64_t m, int64_t n, double* A, int64_t lda, double* tau);
+int  orc_dorgqr(int64_t m, int64_t n, int64_t k, double* A, int64_t lda, const double* tau);
 /* Not in the reference (it has no TRSM, SURVEY.md quick facts): checker for the
  * product's extra capi_dtrsm.  B <- alpha*op(T)^-1*B or alpha*B*op(T)^-1. */
 void orc_dtrsm(int side, int uplo, int trans, int diag, int64_t m, int64_t n, double alpha,

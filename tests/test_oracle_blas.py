@@ -93,3 +93,22 @@ def test_against_mkl_entry_points():
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_mkl_check.py")
     r = subprocess.run([sys.executable, script], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "MKL-OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("m,n", [(40, 40), (120, 33), (17, 29)])
+def test_oracle_householder_qr(oracle, m, n):
+    """orc_dgeqrf / orc_dorgqr (dgeqr2 / dorg2r restated) against numpy's LAPACK-backed QR: |R| agrees (the sign convention
+    of the reflectors is LAPACK's own, so R matches numpy's 'r' mode exactly up to rounding), Q^T Q = I and Q R = A."""
+    rng = np.random.default_rng(m * 100 + n)
+    A = np.asfortranarray(rng.random((m, n)) - 0.5)
+    F = A.copy(order="F")
+    tau = oracle.dgeqrf(F)
+    k = min(m, n)
+    R = np.triu(F[:k, :])
+    Rn = np.linalg.qr(A, mode="r")
+    assert np.abs(R - Rn).max() <= 1e-13
+    if m >= n:
+        Q = F.copy(order="F")
+        oracle.dorgqr(Q, tau)
+        assert np.abs(Q.T @ Q - np.eye(n)).max() <= 1e-14
+        assert np.abs(Q @ R - A).max() <= 1e-14

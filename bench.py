@@ -59,6 +59,23 @@ def cpu_baseline(n_sample):
             "sample": f"n={n_sample} recursive Cholesky, same generator and schedule (bc_mult=-3), oracle/capital_oracle.c, {dt:.1f} s"}
 
 
+def recorded_traffic(n, gpus):
+    """L2-to-fabric bytes per launch of the roofline kernel from the committed PMC passes (FETCH_SIZE + WRITE_SIZE, x2 on
+    gfx950; profiles/README.md).  Counters cannot be read from inside a timed run, so this is the last recorded
+    measurement of the same configuration, or None."""
+    if n != 32768 or gpus != 1:
+        return None, None
+    import csv
+    tot = 0.0
+    try:
+        for tag, name in (("f", "FETCH_SIZE"), ("w", "WRITE_SIZE")):
+            rows = [r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", f"r1_c_pmc_{tag}_bench_step.csv"))) if r["Counter_Name"] == name]
+            tot += sum(float(r["Counter_Value"]) for r in rows[:18]) * 1024 * 2      # KB, 128-B requests counted at 64 B
+    except (OSError, KeyError, ValueError):
+        return None, None
+    return tot / 18.0, "profiles/r1_c_pmc_{f,w}_bench_step.csv: FETCH_SIZE+WRITE_SIZE x2, mean of the 18 launches of one factor()"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,6 +140,7 @@ def main():
     L.capi_prof_collect(h, -1, C.byref(allv[0]), C.byref(allv[1]), C.byref(allv[2]), None)
     residual = prob.residual()
     stats = prob.stats()
+    traffic, traffic_src = recorded_traffic(n, args.gpus)
     prob.close()
 
     out = {
@@ -133,7 +151,7 @@ def main():
         "config": {"workload": f"n={n} recursive Cholesky with inverse (cholinv, complete_inv=0, split=1, bc_mult={args.bc}) on a {prob.d}x{prob.d}x{prob.c} GPU grid",
                    "n": n, "grid": [prob.d, prob.d, prob.c], "base_case_order": stats["bc_dimension"], "residual": residual, "summa_chunks": chunks},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": None,
+                     "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "dgemm_tile_kernel<128,true,true> (trailing update + R12 solve, orders >= 4096)",
                      "launches_per_step": launches.value / max(args.steps, 1),
                      "avg_launch_ms": tot_ms.value / max(launches.value, 1), "max_launch_ms": max_ms.value,

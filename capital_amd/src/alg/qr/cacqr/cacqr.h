@@ -145,12 +145,29 @@ protected:
     CRITTER_STOP(CQR::gram);
     CRITTER_START(CQR::formR);
     CI::factor(G, args.cholesky_inverse_args, sq);                                                                   // cacqr.hpp:103
-    if (!args.cholesky_inverse_args.complete_inv)
-      throw std::logic_error("qr::cacqr 3-D: the blocked solve() for complete_inv == 0 (cacqr.hpp:44-73) is not built; pass complete_inv = 1");
     auto Rinv = CI::construct_Rinv(args.cholesky_inverse_args, sq);
-    matmult::view Tv{Rinv.data(), n_loc, n_loc, n_loc}, Cv{dst, m_loc, m_loc, n_loc};
-    matmult::summa::trmm(sq, CAPI_RIGHT, CAPI_UPPER, CAPI_NOTRANS, CAPI_NONUNIT, 1.0, Tv, Aloc, Cv, ws);               // cacqr.hpp:108-112
-    capital::sync();   // Rinv (a temporary) must outlive the multiply
+    if (args.cholesky_inverse_args.complete_inv) {
+      matmult::view Tv{Rinv.data(), n_loc, n_loc, n_loc}, Cv{dst, m_loc, m_loc, n_loc};
+      matmult::summa::trmm(sq, CAPI_RIGHT, CAPI_UPPER, CAPI_NOTRANS, CAPI_NONUNIT, 1.0, Tv, Aloc, Cv, ws);             // cacqr.hpp:108-112
+      capital::sync();   // Rinv (a temporary) must outlive the multiply
+    } else {
+      // solve (cacqr.hpp:44-73): the top-level R^-1_12 was not formed, so Q = A R^-1 goes block by block over the same
+      // local split cholinv used:  Q1 = A1 R11^-1,  Q2 = (A2 - Q1 R12) R22^-1.
+      // (The reference passes alpha = 1, beta = -1 to the middle product, cacqr.hpp:58, which yields Q1 R12 - A2 and a
+      //  sign-flipped Q2 with Q R != A; the path is outside its validated combinations, SURVEY 8c.  Built to the algebra.)
+      auto Rfull = CI::construct_R(args.cholesky_inverse_args, sq);
+      const int64_t s1 = n_loc >> args.cholesky_inverse_args.split, s2 = n_loc - s1;
+      matmult::view X11{Rinv.data(), n_loc, s1, s1}, X22{Rinv.data() + s1 + s1 * n_loc, n_loc, s2, s2};
+      matmult::view R12{Rfull.data() + s1 * n_loc, n_loc, s1, s2};
+      matmult::view A1{const_cast<double*>(src), m_loc, m_loc, s1}, A2{const_cast<double*>(src) + s1 * m_loc, m_loc, m_loc, s2};
+      matmult::view Q1{dst, m_loc, m_loc, s1}, Q2{dst + s1 * m_loc, m_loc, m_loc, s2};
+      matmult::summa::trmm(sq, CAPI_RIGHT, CAPI_UPPER, CAPI_NOTRANS, CAPI_NONUNIT, 1.0, X11, A1, Q1, ws);
+      matmult::view Tmp{ws.take(m_loc * s2), m_loc, m_loc, s2};
+      capital::dev_copy(Tmp.p, A2.p, m_loc * s2);
+      matmult::summa::gemm(sq, CAPI_NOTRANS, CAPI_NOTRANS, -1.0, Q1, R12, 1.0, Tmp, ws);
+      matmult::summa::trmm(sq, CAPI_RIGHT, CAPI_UPPER, CAPI_NOTRANS, CAPI_NONUNIT, 1.0, X22, Tmp, Q2, ws);
+      capital::sync();   // Rinv / Rfull (temporaries) must outlive the multiplies
+    }
     CRITTER_STOP(CQR::formR);
     ws.top = mark;
   }
@@ -162,7 +179,7 @@ protected:
     const int64_t n = A.num_columns_global(), n_loc = A.num_columns_local(), m_loc = A.num_rows_local();
     matrix<double, int64_t, rect> G(n, n, CommInfo.c, CommInfo.c);
     matmult::arena& ws = matmult::summa::scratch_arena();
-    ws.reserve(6 * m_loc * n_loc + 8 * n_loc * n_loc + 1024);
+    ws.reserve(8 * m_loc * n_loc + 8 * n_loc * n_loc + 1024);
     sweep_3d(A.data(), args.Q.data(), m_loc, n_loc, args, sq, ws, G);
     matrix<double, int64_t, rect> Rfinal = CI::construct_R(args.cholesky_inverse_args, sq);
     if (args.num_iter > 1) {

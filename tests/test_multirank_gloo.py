@@ -129,14 +129,16 @@ def test_cacqr_1d_sharded_rows(oracle, shim_lib, world, m, n, variant, serialize
         assert np.abs(Qg - Qref).max() <= 1e-12 * (1 if variant == 2 else 100)
 
 
-@pytest.mark.parametrize("m,n,variant,serialize,bc", [(512, 32, 2, False, 0), (1000, 48, 2, True, -1), (512, 32, 1, False, 0)])
-def test_cacqr_3d_cubic_grid(oracle, shim_lib, m, n, variant, serialize, bc):
+@pytest.mark.parametrize("m,n,variant,serialize,bc,ci", [(512, 32, 2, False, 0, 1), (1000, 48, 2, True, -1, 1), (512, 32, 1, False, 0, 1),
+                                                         (512, 32, 2, False, -1, 0), (1000, 48, 1, True, -1, 0)])
+def test_cacqr_3d_cubic_grid(oracle, shim_lib, m, n, variant, serialize, bc, ci):
     """c == d == 2 on 8 ranks (cacqr.hpp:75-116,195-215): Gram by Bcast(row)+gemm+Reduce(column)+Bcast(depth), distributed
-    cholinv on the Gram matrix, Q = Q R^-1 by a right-TRMM SUMMA.  Q and R are unique, so the assembled result must equal
-    the 1-D oracle on the assembled input."""
+    cholinv on the Gram matrix, Q = Q R^-1 by a right-TRMM SUMMA -- or, with complete_inv = 0 (ci), by the blocked solve
+    Q1 = A1 R11^-1, Q2 = (A2 - Q1 R12) R22^-1 (cacqr.hpp:44-73).  Q and R are unique, so the assembled result must equal the
+    1-D oracle on the assembled input."""
     world, c, d = 8, 2, 2
     with tempfile.TemporaryDirectory() as dd:
-        _launch(world, {"kind": "cacqr", "m": m, "n": n, "c": c, "variant": variant, "serialize": serialize, "ci": 1, "bc": bc, "dir": dd})
+        _launch(world, {"kind": "cacqr", "m": m, "n": n, "c": c, "variant": variant, "serialize": serialize, "ci": ci, "bc": bc, "dir": dd})
         Ag, Qg, Rg = np.zeros((m, n), order="F"), np.zeros((m, n), order="F"), np.zeros((n, n), order="F")
         for r in range(world):
             z = np.load(os.path.join(dd, f"rank{r}.npz"))

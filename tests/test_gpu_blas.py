@@ -222,3 +222,55 @@ def test_partial_last_round_is_recut_into_64_tiles(n, k):
     # column-major upper triangle == lower triangle of the row-major tensor
     assert (torch.tril(C2) - torch.tril(full)).abs().max().item() <= 1e-13 * full.abs().max().item()
     assert torch.equal(torch.triu(C2, 1), torch.triu(C0, 1))             # the other triangle is untouched
+
+
+def test_randomized_shapes_against_numpy(hip):
+    """120 random cases over every BLAS-level entry point, orders 1..700 (crossing the 32-tile burst kernel, the 64- and
+    128-tile kernels, split-K and the ragged edges of each), odd leading dimensions, all flag combinations; numpy fp64 as
+    the reference, 1e-13 * k relative to the largest entry.  Rows of C beyond m (ld padding) must stay untouched."""
+    from capital_amd import capi
+    rng = np.random.default_rng(20261004)
+    dims = lambda hi=700: int(rng.choice([1, 2, 15, 16, 17, 31, 33, 63, 64, 65, 127, 129, 255, 257, 511, 513, int(rng.integers(1, hi))]))
+    for case in range(120):
+        kind = case % 4
+        pad = int(rng.integers(0, 4))
+        alpha, beta = float(rng.uniform(-2, 2)), float(rng.choice([0.0, 1.0, rng.uniform(-2, 2)]))
+        if kind == 0:                                           # gemm
+            m, n, k, ta, tb = dims(), dims(), dims(), int(rng.integers(2)), int(rng.integers(2))
+            A = _rand(rng, (k if ta else m) + pad, m if ta else k); B = _rand(rng, (n if tb else k) + pad, k if tb else n)
+            Cf = _rand(rng, m + pad, n)
+            opA = A[:k, :].T if ta else A[:m, :]; opB = B[:n, :].T if tb else B[:k, :]
+            ref = alpha * (opA @ opB) + beta * Cf[:m, :]
+            dA, dB, dC = capi.to_device(A), capi.to_device(B), capi.to_device(Cf)
+            hip.call("capi_dgemm", ta, tb, m, n, k, alpha, capi.ptr(dA), A.shape[0], capi.ptr(dB), B.shape[0], beta, capi.ptr(dC), m + pad)
+            got = capi.to_host(dC)
+            _check(got[:m, :], ref, k, np.abs(ref).max())
+        elif kind == 1:                                         # triangular-output gemm (A^T B or A B^T), one triangle only
+            n, k, uplo, ta = dims(), dims(), int(rng.integers(2)), int(rng.integers(2))
+            A = _rand(rng, (k if ta else n) + pad, n if ta else k); B = _rand(rng, (k if ta else n) + pad, n if ta else k)
+            Cf = _rand(rng, n + pad, n)
+            full = alpha * ((A[:k, :].T @ B[:k, :]) if ta else (A[:n, :] @ B[:n, :].T)) + beta * Cf[:n, :]
+            dA, dB, dC = capi.to_device(A), capi.to_device(B), capi.to_device(Cf)
+            hip.call("capi_dgemmt", uplo, ta, 0 if ta else 1, n, k, alpha, capi.ptr(dA), A.shape[0], capi.ptr(dB), B.shape[0], beta, capi.ptr(dC), n + pad)
+            got = capi.to_host(dC)
+            tri = np.triu if uplo == 1 else np.tril
+            other = (lambda x: np.tril(x, -1)) if uplo == 1 else (lambda x: np.triu(x, 1))
+            _check(tri(got[:n, :]), tri(full), k, np.abs(full).max())
+            np.testing.assert_array_equal(other(got[:n, :]), other(Cf[:n, :]))
+            m = n
+        else:                                                   # out-of-place trmm (kind 2: left, 3: right)
+            side = 0 if kind == 2 else 1
+            m, n = dims(), dims()
+            nt = m if side == 0 else n
+            uplo, trans, diag = int(rng.integers(2)), int(rng.integers(2)), int(rng.integers(2))
+            Tf = _rand(rng, nt + pad, nt); B = _rand(rng, m + pad, n); Cf = _rand(rng, m + pad, n)
+            T = np.triu(Tf[:nt, :]) if uplo == 1 else np.tril(Tf[:nt, :])
+            if diag == 1: np.fill_diagonal(T, 1.0)
+            opT = T.T if trans else T
+            ref = alpha * (opT @ B[:m, :] if side == 0 else B[:m, :] @ opT)
+            dT, dB, dC = capi.to_device(Tf), capi.to_device(B), capi.to_device(Cf)
+            hip.call("capi_dtrmm_oop", side, uplo, trans, diag, m, n, alpha, capi.ptr(dT), nt + pad, capi.ptr(dB), m + pad, capi.ptr(dC), m + pad)
+            got = capi.to_host(dC)
+            _check(got[:m, :], ref, nt, np.abs(ref).max() + 1.0)
+        if pad:
+            np.testing.assert_array_equal(got[m:, :], Cf[m:, :])

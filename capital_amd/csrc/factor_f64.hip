@@ -11,6 +11,9 @@
 #include "capi_internal.h"
 
 int capi_ws2_get(capi_handle_t h, size_t bytes, void** p);
+extern "C" int capi_internal_trmm_oop_batched(capi_handle_t h, int side, int uplo, int trans, int diag, int64_t m, int64_t n, double alpha,
+                                              const double* T, int64_t ldt, int64_t st, const double* B, int64_t ldb, int64_t sb,
+                                              double* C, int64_t ldc, int64_t sc, int batch);
 
 namespace {
 
@@ -522,6 +525,50 @@ __global__ void trizero2_kernel(int64_t n, double* __restrict__ A, int64_t lda, 
   }
 }
 
+// The same pair (R, R^-1) for a block of moderate order by a schedule with a shorter dependency chain than the halving
+// recursion above.  Every launch below the order ~2048 is latency-bound, so what counts is the NUMBER of dependent
+// launches: the recursion needs, per 128 columns, a leaf + TRMM + update for the factor AND two TRMMs per tree node for
+// the inverse, all in one chain (2.25 ms at order 2048).  Here
+//   phase 1  right-looking blocked Cholesky, block 128: leaf (R_jj and X_jj = R_jj^-1), row panel R_j,rest = X_jj^T A_j,rest,
+//            trailing update A_rest,rest -= R_j,rest^T R_j,rest -- 3 dependent launches + 1 copy per 128 columns;
+//   phase 2  the inverse's off-diagonal blocks level by level (X12 = -X11 R12 X22 at block sizes 128, 256, ...): all pairs
+//            of a level are independent and go out as ONE strided-batch launch per product -- 2 log2(n/128) launches.
+// `W`: scratch of 128 * n + n * n / 4 doubles.
+int potrf_trtri_blocked(capi_handle_t h, int64_t n, double* A, int64_t lda, double* X, int64_t ldx, int info_base, double* W) {
+  const int64_t nblk = cdiv(n, (int64_t)LEAF);
+  for (int64_t j = 0; j < nblk; ++j) {
+    const int64_t j0 = j * LEAF, jb = (n - j0) < LEAF ? (n - j0) : LEAF, rest = n - j0 - jb;
+    double* Ajj = A + j0 + j0 * lda;
+    double* Xjj = X + j0 + j0 * ldx;
+    RC(leaf_launch(h, Ajj, lda, Xjj, ldx, (int)jb, 1, 0, 0, 0, info_base + (int)j0));
+    if (rest > 0) {
+      double* Ajr = A + j0 + (j0 + jb) * lda;
+      RC(capi_dtrmm_oop(h, CAPI_LEFT, CAPI_UPPER, CAPI_TRANS, CAPI_NONUNIT, jb, rest, 1.0, Xjj, ldx, Ajr, lda, W, jb));
+      RC(capi_dlacpy(h, 0, jb, rest, W, jb, Ajr, lda));
+      RC(capi_dgemmt(h, CAPI_UPPER, CAPI_TRANS, CAPI_NOTRANS, rest, jb, -1.0, W, jb, W, jb, 1.0, A + (j0 + jb) + (j0 + jb) * lda, lda));
+    }
+  }
+  double* T = W + (int64_t)LEAF * n;
+  for (int64_t b = LEAF; b < n; b *= 2) {
+    const int64_t full = n / (2 * b);                      // pairs whose second block is complete
+    if (full > 0) {
+      // pair p: X11 = X(p 2b, p 2b), R12 = A(p 2b, p 2b + b), X22 = X(p 2b + b, p 2b + b), X12 = X(p 2b, p 2b + b); T_p = T + p b b
+      RC(capi_internal_trmm_oop_batched(h, CAPI_LEFT, CAPI_UPPER, CAPI_NOTRANS, CAPI_NONUNIT, b, b, 1.0, X, ldx, 2 * b * (ldx + 1),
+                                        A + b * lda, lda, 2 * b * (lda + 1), T, b, b * b, (int)full));
+      RC(capi_internal_trmm_oop_batched(h, CAPI_RIGHT, CAPI_UPPER, CAPI_NOTRANS, CAPI_NONUNIT, b, b, -1.0, X + b + b * ldx, ldx,
+                                        2 * b * (ldx + 1), T, b, b * b, X + b * ldx, ldx, 2 * b * (ldx + 1), (int)full));
+    }
+    const int64_t p0 = full * 2 * b;                        // a last pair with a short second block
+    if (p0 + b < n) {
+      const int64_t n2 = n - p0 - b;
+      RC(capi_dtrmm_oop(h, CAPI_LEFT, CAPI_UPPER, CAPI_NOTRANS, CAPI_NONUNIT, b, n2, 1.0, X + p0 + p0 * ldx, ldx, A + p0 + (p0 + b) * lda, lda, T, b));
+      RC(capi_dtrmm_oop(h, CAPI_RIGHT, CAPI_UPPER, CAPI_NOTRANS, CAPI_NONUNIT, b, n2, -1.0, X + (p0 + b) + (p0 + b) * ldx, ldx, T, b,
+                        X + p0 + (p0 + b) * ldx, ldx));
+    }
+  }
+  return CAPI_OK;
+}
+
 // in-place inverse of an upper triangular matrix (non-unit or unit diagonal)
 int trtri_upper_rec(capi_handle_t h, int diag, int64_t n, double* T, int64_t ldt) {
   if (n <= LEAF) return leaf_launch(h, T, ldt, T, ldt, (int)n, 1, 0, 1, diag == CAPI_UNIT, 0);
@@ -620,12 +667,17 @@ int capi_dpotrf_trtri(capi_handle_t h, int64_t n, double* A, int64_t lda, double
   if (n == 0) return CAPI_OK;
   CAPI_REQUIRE(h, A && Rinv && lda >= n && ldi >= n, "operands");
   if (n <= LEAF) return leaf_launch(h, A, lda, Rinv, ldi, (int)n, 1, 1, 0, 0, 0);
-  { void* w; RC(capi_ws2_get(h, sizeof(double) * (size_t)(n / 2 + LEAF) * (size_t)(n / 2 + LEAF), &w)); }
+  void* w;
+  RC(capi_ws2_get(h, sizeof(double) * ((size_t)(n / 2 + LEAF) * (size_t)(n / 2 + LEAF) + (size_t)LEAF * (size_t)n), &w));
   {
     dim3 grid((unsigned)cdiv(n, 256), (unsigned)(n < 65535 ? n : 65535));
     hipLaunchKernelGGL(trizero2_kernel, grid, dim3(256), 0, h->stream, n, A, lda, Rinv, ldi);
     CAPI_HIP_CHECK(h, hipGetLastError());
   }
+  // up to order 4096 the blocked schedule's shorter launch chain wins; above, the recursion's large products do
+  static const char* force = getenv("CAPI_POTRF_TRTRI");   // "rec" | "blocked": diagnostics
+  const bool blocked = force ? force[0] == 'b' : n <= 4096;
+  if (blocked) return potrf_trtri_blocked(h, n, A, lda, Rinv, ldi, 0, (double*)w);
   return potrf_trtri_rec(h, n, A, lda, Rinv, ldi, 0, 0);
 }
 

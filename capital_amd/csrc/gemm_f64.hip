@@ -62,6 +62,8 @@ struct GemmArgs {
   double* slab;       // split-K partial sums: slab[z*slab_stride + i + j*slab_ld]
   int64_t slab_ld, slab_stride;
   int tiles_m, tiles_n, ntiles;
+  int batch;          // burst-load kernel only: blockIdx.y indexes `batch` independent products, operands sa/sb/sc elements apart
+  int64_t sa, sb, sc;
   int tail_base, tail_tm, tail_tn;   // > 0: this 64-tile launch covers the four quarters of the 128-tiles [tail_base, ...) of a tail_tm x tail_tn tiling
   int ts;             // tile size chosen by the launcher
   int no_skip;        // diagnostics: never skip zero sub-tiles
@@ -552,8 +554,13 @@ __device__ __forceinline__ void small_store(double* __restrict__ L, int tid, int
 }
 
 template <bool AK, bool BKC>
-__global__ __launch_bounds__(256, 1) void dgemm_small_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(256, 1) void dgemm_small_kernel(const GemmArgs pin) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  GemmArgs p = pin;
+  if (p.batch > 1) {                           // strided batch: same shapes, operands a fixed stride apart
+    const int64_t bz = blockIdx.y;
+    p.A += bz * p.sa; p.B += bz * p.sb; p.C += bz * p.sc;
+  }
   double* La = lds;
   double* Lb = lds + SKC * SLD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1030,7 +1037,7 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
         CAPI_HIP_CHECK(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         attr_set[vi] = true;
       }
-      hipLaunchKernelGGL(k, dim3((unsigned)p.ntiles), dim3(256), lds_bytes, s, p);
+      hipLaunchKernelGGL(k, dim3((unsigned)p.ntiles, (unsigned)(p.batch > 1 ? p.batch : 1)), dim3(256), lds_bytes, s, p);
       CAPI_HIP_CHECK(h, hipGetLastError());
       return CAPI_OK;
     }
@@ -1213,6 +1220,33 @@ static int trmm_launch(capi_handle_t h, int side, int uplo, int trans, int diag,
     p.A = B; p.lda = ldb; p.B = T; p.ldb = ldt;
     return launch_gemm(h, false, trans == CAPI_NOTRANS, p, ws_free);
   }
+}
+
+// `batch` independent out-of-place TRMMs of one shape whose operands sit a fixed stride apart (the off-diagonal blocks
+// of one level of a triangular inverse): ONE launch of the burst-load kernel when it serves the shape, a loop otherwise.
+__attribute__((visibility("hidden"))) int capi_internal_trmm_oop_batched(capi_handle_t h, int side, int uplo, int trans, int diag,
+                                                                           int64_t m, int64_t n, double alpha, const double* T,
+                                                                           int64_t ldt, int64_t st, const double* B, int64_t ldb,
+                                                                           int64_t sb_, double* C, int64_t ldc, int64_t sc_, int batch) {
+  const bool small_ok = m <= 512 && n <= 512 && !getenv("CAPI_SMALL");
+  const bool aligned = ((st | sb_ | sc_) & 1) == 0;      // keeps the 16-byte alignment decision valid for every batch member
+  if (batch > 1 && small_ok && aligned) {
+    const int64_t nt = side == CAPI_LEFT ? m : n;
+    GemmArgs p{};
+    p.C = C; p.ldc = ldc; p.M = (int)m; p.N = (int)n; p.K = (int)nt; p.alpha = alpha; p.beta = 0.0;
+    p.out_uplo = -1; p.tri_side = side;
+    p.tri_eff_upper = ((uplo == CAPI_UPPER) != (trans == CAPI_TRANS));
+    p.tri_unit = diag == CAPI_UNIT;
+    p.batch = batch;
+    if (side == CAPI_LEFT) { p.A = T; p.lda = ldt; p.sa = st; p.B = B; p.ldb = ldb; p.sb = sb_; p.sc = sc_; return launch_gemm(h, trans == CAPI_TRANS, true, p, true); }
+    p.A = B; p.lda = ldb; p.sa = sb_; p.B = T; p.ldb = ldt; p.sb = st; p.sc = sc_;
+    return launch_gemm(h, false, trans == CAPI_NOTRANS, p, true);
+  }
+  for (int b = 0; b < batch; ++b) {
+    int rc = capi_dtrmm_oop(h, side, uplo, trans, diag, m, n, alpha, T + b * st, ldt, B + b * sb_, ldb, C + b * sc_, ldc);
+    if (rc != CAPI_OK) return rc;
+  }
+  return CAPI_OK;
 }
 
 int capi_dtrmm_oop(capi_handle_t h, int side, int uplo, int trans, int diag, int64_t m, int64_t n, double alpha,

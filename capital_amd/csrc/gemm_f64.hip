@@ -562,7 +562,7 @@ __global__ __launch_bounds__(256, 1) void dgemm_small_kernel(const GemmArgs pin)
     p.A += bz * p.sa; p.B += bz * p.sb; p.C += bz * p.sc;
   }
   double* La = lds;
-  double* Lb = lds + SKC * SLD;
+  double* Lb = lds + p.ts * SLD;               // p.ts carries the staged depth here: min(256, K rounded up to 64) rows per operand
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, g = lane >> 4, wm = wave & 1, wn = wave >> 1;
   const int ti = blockIdx.x % p.tiles_m, tj = blockIdx.x / p.tiles_m;
@@ -1019,10 +1019,18 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
     const double chunks = keff / SKC < 1.0 ? 1.0 : keff / SKC;
     const double t_small = (double)cdiv((int64_t)nt32, h->num_cu) * (chunks * 2.0 + keff * (16.0 / 2200.0) * 4.0 / 4.0) + 3.0;
     bool use_small = p.M <= 512 && p.N <= 512 && p.K <= 2048;      // measured: 1.5-2x faster up to order 512, slower from 1024
+    // thin products of the blocked factorization (K <= 256: a 128-row panel against up to ~2000 columns, its trailing
+    // update): one staged chunk, LDS sized by K, so two workgroups share a CU at K <= 128
+    static const int thin_rounds = getenv("CAPI_THIN_ROUNDS") ? atoi(getenv("CAPI_THIN_ROUNDS")) : 3;
+    if (!use_small && p.K <= SKC && p.batch <= 1) {
+      const double slots = (double)h->num_cu * (p.K <= 128 ? 2.0 : 1.0);
+      use_small = nt32 <= thin_rounds * slots;
+    }
     if (force_small) use_small = atoi(force_small) != 0 && p.M <= 4096 && p.N <= 4096;
     if (dbg) fprintf(stderr, "[capi gemm]   small-kernel estimate %.1f us -> %s\n", t_small, use_small ? "small" : "tile");
     if (use_small) {
-      p.ts = ST;
+      const int kcap = p.K >= SKC ? SKC : (int)(cdiv(p.K, SQK) * SQK);      // staged depth: LDS holds 2 x kcap x SLD doubles
+      p.ts = kcap;
       p.tiles_m = (int)cdiv(p.M, ST);
       p.tiles_n = (int)cdiv(p.N, ST);
       p.ntiles = p.tiles_m * p.tiles_n;
@@ -1030,11 +1038,11 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
       p.b_vec = (((uintptr_t)p.B & 15) == 0) && ((p.ldb & 1) == 0);
       p.splitk = 1;
       gemm_kernel_t k = pick_small(ak, bkc);
-      const size_t lds_bytes = sizeof(double) * 2 * SKC * SLD;
+      const size_t lds_bytes = sizeof(double) * 2 * (size_t)kcap * SLD;
       static bool attr_set[4] = {false, false, false, false};
       const int vi = (ak ? 2 : 0) + (bkc ? 1 : 0);
       if (!attr_set[vi]) {
-        CAPI_HIP_CHECK(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        CAPI_HIP_CHECK(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * 2 * SKC * SLD)));
         attr_set[vi] = true;
       }
       hipLaunchKernelGGL(k, dim3((unsigned)p.ntiles, (unsigned)(p.batch > 1 ? p.batch : 1)), dim3(256), lds_bytes, s, p);

@@ -218,8 +218,8 @@ public:
       for (size_t s = 0; s < steps; ++s) {
         const size_t q = t.z + s * t.c;
         view tt, bb;
-        if (side == CAPI_LEFT) { tt = panel(t.row, t.x == q, (int)q, T, ws); bb = panel(t.column, t.y == q, (int)q, B, ws); }
-        else { bb = panel(t.row, t.x == q, (int)q, B, ws); tt = panel(t.column, t.y == q, (int)q, T, ws); }
+        if (side == CAPI_LEFT) { tt = panel_tri(t.row, t.x == q, (int)q, T, uplo, ws); bb = panel(t.column, t.y == q, (int)q, B, ws); }
+        else { bb = panel(t.row, t.x == q, (int)q, B, ws); tt = panel_tri(t.column, t.y == q, (int)q, T, uplo, ws); }
         CAPITAL_CHECK(capi_dtrmm_acc(h, side, uplo, trans, diag, M, N, alpha, tt.p, tt.ld, bb.p, bb.ld, s ? 1.0 : 0.0, Cout.p, Cout.ld));
       }
     } else {
@@ -312,8 +312,8 @@ public:
         }
       }
       if (t.c > 1) {
-        // only the computed triangle is folded into C
-        CAPITAL_CHECK(capi_allreduce_sum(t.depth, acc.p, acc.count()));
+        // only the computed triangle is folded into C (and only it travels)
+        allreduce_tri(t.depth, acc, uplo, ws);
         CAPITAL_CHECK(capi_dgeadd(h, uplo == CAPI_UPPER ? 1 : 2, N, N, 1.0, acc.p, acc.ld, beta, C.p, C.ld));
       }
       ws.top = mark;
@@ -405,6 +405,38 @@ public:
     }
     CAPITAL_CHECK(capi_bcast(comm, out.p, out.count(), root));
     return out;
+  }
+  // A TRIANGULAR operand travels packed (n(n+1)/2 doubles instead of n^2, the reference's Serialize policy on the wire,
+  // summa.hpp:147-148,216-217): the root packs, everyone unpacks the triangle into a full-stride buffer whose other half is
+  // never read (the kernels truncate each tile's k-range at the diagonal and mask the diagonal panels by selection).
+  static view panel_tri(capi_comm_t comm, bool is_root, int root, const view& mine, int uplo, arena& ws) {
+    int size = 1;
+    CAPITAL_CHECK(capi_comm_size(comm, &size));
+    if (size == 1) return mine;
+    static const bool off = getenv("CAPITAL_NO_PACKED_COMM") != nullptr;
+    if (off || mine.rows != mine.cols) return panel(comm, is_root, root, mine, ws);
+    capi_handle_t h = capital::handle();
+    const int64_t n = mine.rows, np = n * (n + 1) / 2;
+    const int st = uplo == CAPI_UPPER ? CAPI_UPPERTRI : CAPI_LOWERTRI;
+    double* packed = ws.take(np);
+    if (is_root) CAPITAL_CHECK(capi_serialize_shape(h, st, CAPI_RECT, st, mine.p, n, mine.ld, packed, n, n, 0, n, 0, n, 0, n, 0, n));
+    CAPITAL_CHECK(capi_bcast(comm, packed, np, root));
+    if (is_root) return mine;                                   // the root multiplies with its own block
+    view out{ws.take(n * n), n, n, n};
+    CAPITAL_CHECK(capi_serialize_shape(h, st, st, CAPI_RECT, packed, n, n, out.p, n, n, 0, n, 0, n, 0, n, 0, n));
+    return out;
+  }
+  // sum over `comm` of the `uplo` triangle of a contiguous n x n accumulator, packed on the wire
+  static void allreduce_tri(capi_comm_t comm, view acc, int uplo, arena& ws) {
+    static const bool off = getenv("CAPITAL_NO_PACKED_COMM") != nullptr;
+    if (off || acc.rows != acc.cols || !acc.contiguous()) { CAPITAL_CHECK(capi_allreduce_sum(comm, acc.p, acc.count())); return; }
+    capi_handle_t h = capital::handle();
+    const int64_t n = acc.rows, np = n * (n + 1) / 2;
+    const int st = uplo == CAPI_UPPER ? CAPI_UPPERTRI : CAPI_LOWERTRI;
+    double* packed = ws.take(np);
+    CAPITAL_CHECK(capi_serialize_shape(h, st, CAPI_RECT, st, acc.p, n, n, packed, n, n, 0, n, 0, n, 0, n, 0, n));
+    CAPITAL_CHECK(capi_allreduce_sum(comm, packed, np));
+    CAPITAL_CHECK(capi_serialize_shape(h, st, st, CAPI_RECT, packed, n, n, acc.p, n, n, 0, n, 0, n, 0, n, 0, n));
   }
   static void allreduce_view(capi_comm_t comm, view v, arena& ws) {
     if (v.contiguous()) { CAPITAL_CHECK(capi_allreduce_sum(comm, v.p, v.count())); return; }

@@ -210,8 +210,20 @@ private:
       } else {
         // partner-exchanged copy of R11^-1 (cholinv.hpp:116-117)
         view Tx{ws.take((int64_t)split1 * split1), split1, split1, split1};
-        CAPITAL_CHECK(capi_dlacpy(h, 0, split1, split1, R11i.p, ld, Tx.p, Tx.ld));
-        util::transpose_raw(Tx.p, Tx.count(), ws.take(Tx.count()), t);
+        if (t.x == t.y || getenv("CAPITAL_NO_PACKED_COMM")) {
+          CAPITAL_CHECK(capi_dlacpy(h, 0, split1, split1, R11i.p, ld, Tx.p, Tx.ld));
+          util::transpose_raw(Tx.p, Tx.count(), ws.take(Tx.count()), t);
+        } else {
+          // the exchanged block is upper triangular: it crosses the link packed (n(n+1)/2) and is unpacked on arrival;
+          // the strictly-lower half of Tx is never read (TRMM masks by selection)
+          const int64_t np = (int64_t)split1 * (split1 + 1) / 2;
+          double* pk = ws.take(np);
+          CAPITAL_CHECK(capi_serialize_shape(h, CAPI_UPPERTRI, CAPI_RECT, CAPI_UPPERTRI, R11i.p, split1, ld, pk, split1, split1,
+                                             0, split1, 0, split1, 0, split1, 0, split1));
+          util::transpose_raw(pk, np, ws.take(np), t);
+          CAPITAL_CHECK(capi_serialize_shape(h, CAPI_UPPERTRI, CAPI_UPPERTRI, CAPI_RECT, pk, split1, split1, Tx.p, split1, split1,
+                                             0, split1, 0, split1, 0, split1, 0, split1));
+        }
         matmult::summa::trmm(t, CAPI_LEFT, CAPI_UPPER, CAPI_TRANS, CAPI_NONUNIT, 1.0, Tx, A12, W, ws);
       }
       CAPITAL_CHECK(capi_dlacpy(h, 0, split1, split2, W.p, W.ld, A12.p, ld));            // R12 into R (cholinv.hpp:122)

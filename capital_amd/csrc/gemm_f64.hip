@@ -44,6 +44,10 @@ template <int TS> struct tile_cfg {
   static constexpr int SUB = TS / 32;               // MFMA tiles per wave per dimension
 };
 constexpr int GROUP_M = 8;
+#ifndef CAPI_STORE_IN_SHADOW
+#define CAPI_STORE_IN_SHADOW 1
+#endif
+constexpr bool STORE_IN_SHADOW = CAPI_STORE_IN_SHADOW;
 
 struct GemmArgs {
   const double* A;
@@ -389,9 +393,22 @@ __global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel
       __builtin_amdgcn_s_setprio(1);      // keeps the cluster contiguous (+1 % measured)
       mfma_step<SUB, 0, FAST>(acc, af, bf, keep);
       mfma_step<SUB, 1, FAST>(acc, af, bf, keep);
+      if (FAST && STORE_IN_SHADOW && u == 1) {
+        // the staging stores of the next panel are issued in the shadow of this half's MFMAs (one LDS write per few
+        // MFMAs) instead of behind them: the prefetch landed thousands of cycles ago, and the pipe stays fed while the
+        // wave issues them.  (B is staged even on a shared diagonal tile, where nobody reads it: no branch in the block.)
+        double* Na = lds + (par ^ 1) * STAGE_LDS;
+        panel_store<TS, AK>(Na, tid, ra);
+        panel_store<TS, BKC>(Na + TILE_LDS, tid, rb);
+#pragma unroll
+        for (int i = 0; i < 2 * NQ; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, (2 * SUB * SUB) / (2 * NQ), 0);   // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                           // DS write
+        }
+      }
       __builtin_amdgcn_s_setprio(0);
     }
-    if (more) {
+    if (more && !(FAST && STORE_IN_SHADOW)) {
       if (!FAST) {
         if (maskA && kn < i0 + BM && kn + BK > i0) panel_mask<TS, AK>(i0, kn, tid, keep_ge, p.tri_unit, ra);
         if (maskB && kn < j0 + BN && kn + BK > j0) panel_mask<TS, BKC>(j0, kn, tid, keep_ge, p.tri_unit, rb);

@@ -1,18 +1,18 @@
 """From a rocprofv3 kernel_trace.csv of `python bench.py --steps K --warmup W`: average duration of one kernel symbol over
-the launches that fall inside bench.py's timed region (the last K factor() calls), for comparison with the HIP-event
-average bench.py prints in roofline.avg_launch_ms.   usage: timed_region_stats.py trace.csv K [symbol-substring]"""
+the launches that fall inside bench.py's timed region (the last K of the first W+K factor() calls), for comparison with
+the HIP-event average bench.py prints in roofline.avg_launch_ms.
+usage: timed_region_stats.py trace.csv K [W=1] [symbol-substring]
+A factor() call issues exactly five packing kernels (serialize_kernel: three beside the top-level update, two at its end),
+so call i ends with the 5(i+1)-th serialize_kernel of the process."""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-K = int(sys.argv[2]); sym = sys.argv[3] if len(sys.argv) > 3 else "dgemm_tile_kernel<128, true, true>"
+K = int(sys.argv[2]); W = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+sym = sys.argv[4] if len(sys.argv) > 4 else "dgemm_tile_kernel<128, true, true>"
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# a factor() call opens with lacpy_kernel (upper-triangle copy of the input's leading block) followed by leaf kernels
-starts = [i for i, r in enumerate(rows) if "lacpy_kernel" in r["Kernel_Name"]]
-calls = []
-for a, b in zip(starts, starts[1:] + [len(rows)]):
-    if sum("leaf128" in r["Kernel_Name"] for r in rows[a:b]) >= 8:
-        seg = rows[a:b]
-        ser = [i for i, r in enumerate(seg) if "serialize_kernel" in r["Kernel_Name"]]
-        calls.append(seg[: ser[4] + 1] if len(ser) >= 5 else seg)       # a call ends with its 3 early + 2 late packing kernels
-timed = [r for seg in calls[-K:] for r in seg if sym in r["Kernel_Name"]]
+ser = [i for i, r in enumerate(rows) if "serialize_kernel" in r["Kernel_Name"]]
+assert len(ser) >= 5 * (W + K), "fewer packing kernels than W+K factor() calls"
+ends = [ser[5 * (c + 1) - 1] for c in range(W + K)]
+a, b = ends[W - 1] + 1 if W > 0 else 0, ends[W + K - 1]
+timed = [r for r in rows[a:b + 1] if sym in r["Kernel_Name"]]
 d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in timed]
-print(f"{sym}: {len(d)} launches in the last {K} factor() calls, {len(d) / K:.1f} per call, average {sum(d) / len(d) / 1e6:.4f} ms, max {max(d) / 1e6:.3f} ms")
+print(f"{sym}: {len(d)} launches in the {K} timed factor() calls, {len(d) / K:.1f} per call, average {sum(d) / len(d) / 1e6:.4f} ms, max {max(d) / 1e6:.3f} ms")

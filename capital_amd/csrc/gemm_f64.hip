@@ -704,6 +704,12 @@ __device__ __forceinline__ void gram_ts_body(const GemmArgs& p, double* __restri
     }
   };
   auto stage = [&](double* L, int pnl, const d2_t (&st)[4]) {
+    // workgroup-uniform fast path: no branch (and so no conservative s_waitcnt vmcnt(0) at a join) around the LDS stores
+    if (FULLW && p.a_vec && (pnl + 1) * BK <= p.K) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *(d2_t*)&L[(c0 + 64 * q) * SK + 2 * kp] = st[q];
+      return;
+    }
     const int k = pnl * BK + 2 * kp;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -852,17 +858,19 @@ __device__ __forceinline__ void trmm_ts_body(const GemmArgs& p, double* __restri
     for (int q = 0; q < 4; ++q) st[q] = *(const d2_t*)(src + 2 * q);
   };
   auto stage = [&](double* L, int tile, const d2_t (&st)[4]) {
-    const int row0 = 16 * tile + 8 * lh;
-    const bool in = row0 + 8 <= p.M && p.a_vec;
+    // workgroup-uniform fast path: no branch (and so no conservative s_waitcnt vmcnt(0) at a join) around the LDS stores
+    if (p.a_vec && 16 * tile + 16 <= p.M) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      d2_t v = st[q];
-      if (!in) {                                            // ragged last tile / unaligned A: scalar reads
-        const int r = row0 + 2 * q;
-        v = (d2_t){0.0, 0.0};
-        if (r < p.M) v.x = p.A[r + (int64_t)lk * p.lda];
-        if (r + 1 < p.M) v.y = p.A[r + 1 + (int64_t)lk * p.lda];
-      }
+      for (int q = 0; q < 4; ++q) *(d2_t*)&L[lk * 16 + 8 * lh + 2 * q] = st[q];
+      return;
+    }
+    const int row0 = 16 * tile + 8 * lh;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                           // ragged last tile / unaligned A: scalar reads
+      const int r = row0 + 2 * q;
+      d2_t v = {0.0, 0.0};
+      if (r < p.M) v.x = p.A[r + (int64_t)lk * p.lda];
+      if (r + 1 < p.M) v.y = p.A[r + 1 + (int64_t)lk * p.lda];
       *(d2_t*)&L[lk * 16 + 8 * lh + 2 * q] = v;
     }
   };
@@ -887,18 +895,21 @@ __device__ __forceinline__ void trmm_ts_body(const GemmArgs& p, double* __restri
     par ^= 1;
     __syncthreads();
     // lane holds (i = row r16 of the tile, j = 16 strip + g + 4 reg): 16 lanes -> 128 contiguous bytes of one column
+    // (beta is tested ONCE: a per-store `if (beta != 0) r += beta * *c` puts a load in a branch before every store, and
+    //  the compiler then parks an s_waitcnt vmcnt(0) at each join -- eight full drains of the prefetch queue per tile)
     const int i = 16 * tile + r16;
     if (i < p.M) {
+      double* c0_ = p.C + i + (int64_t)(16 * SA + g) * p.ldc;
+      double* c1_ = p.C + i + (int64_t)(16 * SB + g) * p.ldc;
+      const int64_t s4 = 4 * p.ldc;
+      if (p.beta == 0.0) {
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const d4_t& v = half ? cb : ca;
-        double* c = p.C + i + (int64_t)(16 * (half ? SB : SA) + g) * p.ldc;
+        for (int reg = 0; reg < 4; ++reg) { c0_[reg * s4] = p.alpha * ca[reg]; c1_[reg * s4] = p.alpha * cb[reg]; }
+      } else {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-          double r = p.alpha * v[reg];
-          if (p.beta != 0.0) r += p.beta * (*c);
-          *c = r;
-          c += 4 * p.ldc;
+          c0_[reg * s4] = p.alpha * ca[reg] + p.beta * c0_[reg * s4];
+          c1_[reg * s4] = p.alpha * cb[reg] + p.beta * c1_[reg * s4];
         }
       }
     }

@@ -479,31 +479,60 @@ __global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel
     }
   }
 
-  // epilogue: lane holds C[i = ..+r16][j = ..+g+4*reg]; 16 lanes -> 128 contiguous bytes of one column
-  const bool to_slab = p.splitk > 1;
+  // epilogue: lane holds C[i = ..+r16][j = ..+g+4*reg]; 16 lanes -> 128 contiguous bytes of one column.
+  // beta is tested once, and with beta != 0 the old values of a whole row of sub-tiles are requested together before any
+  // store: a per-element `if (beta != 0) r += beta * *c` is a load in a branch in front of every store, i.e. 64 serialised
+  // memory round trips per thread (it dominated the K = 128 trailing updates of the blocked factorization).
+  auto element_ok = [&](int i, int j) {
+    bool ok = (i < p.M) && (j < p.N);
+    if (p.out_uplo == CAPI_UPPER) ok = ok && (i <= j);
+    if (p.out_uplo == CAPI_LOWER) ok = ok && (i >= j);
+    return ok;
+  };
+  if (p.splitk > 1) {
 #pragma unroll
-  for (int a = 0; a < SUB; ++a) {
-    const int i = i0 + wm * (TS / 2) + a * 16 + r16;
+    for (int a = 0; a < SUB; ++a) {
+      const int i = i0 + wm * (TS / 2) + a * 16 + r16;
 #pragma unroll
-    for (int b = 0; b < SUB; ++b) {
+      for (int b = 0; b < SUB; ++b)
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int j = j0 + wn * (TS / 2) + b * 16 + g + 4 * reg;
-        bool ok = (i < p.M) && (j < p.N);
-        if (p.out_uplo == CAPI_UPPER) ok = ok && (i <= j);
-        if (p.out_uplo == CAPI_LOWER) ok = ok && (i >= j);
-        if (ok) {
-          const double v = acc[a][b][reg];
-          if (to_slab) {
-            p.slab[(int64_t)z * p.slab_stride + i + (int64_t)j * p.slab_ld] = v;
-          } else {
-            double* c = p.C + i + (int64_t)j * p.ldc;
-            double r = p.alpha * v;
-            if (p.beta != 0.0) r += p.beta * (*c);
-            *c = r;
-          }
+        for (int reg = 0; reg < 4; ++reg) {
+          const int j = j0 + wn * (TS / 2) + b * 16 + g + 4 * reg;
+          if (element_ok(i, j)) p.slab[(int64_t)z * p.slab_stride + i + (int64_t)j * p.slab_ld] = acc[a][b][reg];
         }
-      }
+    }
+  } else if (p.beta == 0.0) {
+#pragma unroll
+    for (int a = 0; a < SUB; ++a) {
+      const int i = i0 + wm * (TS / 2) + a * 16 + r16;
+#pragma unroll
+      for (int b = 0; b < SUB; ++b)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int j = j0 + wn * (TS / 2) + b * 16 + g + 4 * reg;
+          if (element_ok(i, j)) p.C[i + (int64_t)j * p.ldc] = p.alpha * acc[a][b][reg];
+        }
+    }
+  } else {
+#pragma unroll
+    for (int a = 0; a < SUB; ++a) {
+      const int i = i0 + wm * (TS / 2) + a * 16 + r16;
+      double old[SUB][4];
+#pragma unroll
+      for (int b = 0; b < SUB; ++b)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int j = j0 + wn * (TS / 2) + b * 16 + g + 4 * reg;
+          const bool ok = element_ok(i, j);
+          old[b][reg] = *(ok ? p.C + i + (int64_t)j * p.ldc : p.C);      // unconditional load from a clamped address
+        }
+#pragma unroll
+      for (int b = 0; b < SUB; ++b)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int j = j0 + wn * (TS / 2) + b * 16 + g + 4 * reg;
+          if (element_ok(i, j)) p.C[i + (int64_t)j * p.ldc] = p.alpha * acc[a][b][reg] + p.beta * old[b][reg];
+        }
     }
   }
 }
@@ -644,18 +673,21 @@ __global__ __launch_bounds__(256, 1) void dgemm_small_kernel(const GemmArgs pin)
     }
   }
   const int i = i0 + wm * 16 + r16;
+  double old[4];
+  bool okv[4];
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) {
     const int j = j0 + wn * 16 + g + 4 * reg;
     bool ok = (i < p.M) && (j < p.N);
     if (p.out_uplo == CAPI_UPPER) ok = ok && (i <= j);
     if (p.out_uplo == CAPI_LOWER) ok = ok && (i >= j);
-    if (ok) {
-      double* c = p.C + i + (int64_t)j * p.ldc;
-      double r = p.alpha * acc[reg];
-      if (p.beta != 0.0) r += p.beta * (*c);
-      *c = r;
-    }
+    okv[reg] = ok;
+    old[reg] = (p.beta != 0.0) ? *(ok ? p.C + i + (int64_t)j * p.ldc : p.C) : 0.0;   // beta uniform: loads issued together
+  }
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const int j = j0 + wn * 16 + g + 4 * reg;
+    if (okv[reg]) p.C[i + (int64_t)j * p.ldc] = p.alpha * acc[reg] + (p.beta != 0.0 ? p.beta * old[reg] : 0.0);
   }
 }
 

@@ -576,9 +576,12 @@ typedef void (*gemm_kernel_t)(const GemmArgs);
 // MFMA tile each -- one exposed memory latency per 256 of K instead of one per 16, and 16x more workgroups per output.
 constexpr int ST = 32, SKC = 256, SQK = 64, SLD = ST + 2;
 
+// Issue only: unconditional 16-byte loads from clamped addresses.  Everything that depends on the loaded values (edge
+// fix-ups, the triangle mask) lives in small_fix, called right before the quarter is staged -- a load inside a branch makes
+// the compiler park an s_waitcnt vmcnt(0) at the join, and the "burst" of 32 loads then ran as 32 serialised round trips.
 template <bool KC>
 __device__ __forceinline__ void small_load(const double* __restrict__ X, int64_t ld, int r0, int R, int kc, int kend, int tid,
-                                           bool vec_ok, bool tri, bool keep_ge, bool unit, int quarter, d2_t (&v)[16]) {
+                                           bool vec_ok, int quarter, d2_t (&v)[16]) {
   // KC (k contiguous): row = tid>>3, k = kc + 2*(tid&7) + 16*q.   else (row contiguous): rows 2*(tid&15)+{0,1}, k = kc + (tid>>4) + 16*q
 #pragma unroll
   for (int qq = 0; qq < 4; ++qq) {
@@ -587,10 +590,39 @@ __device__ __forceinline__ void small_load(const double* __restrict__ X, int64_t
     if (KC) { r[0] = r[1] = r0 + (tid >> 3); k[0] = kc + 2 * (tid & 7) + 16 * q; k[1] = k[0] + 1; }
     else { r[0] = r0 + 2 * (tid & 15); r[1] = r[0] + 1; k[0] = k[1] = kc + (tid >> 4) + 16 * q; }
     const double* ptr = KC ? X + (int64_t)r[0] * ld + k[0] : X + (int64_t)k[0] * ld + r[0];
-    d2_t val = {0.0, 0.0};
-    if (r[1] < R && k[1] < kend && vec_ok) {
-      val = *(const d2_t*)ptr;
-    } else {
+    const bool in = r[1] < R && k[1] < kend && vec_ok;
+    v[q] = *(const d2_t*)(in ? ptr : X);
+  }
+}
+
+// interior, aligned chunk: one pointer, a constant stride between the 16 pieces, a piece-uniform range test -- nothing
+// between the 32 load instructions but address increments
+template <bool KC>
+__device__ __forceinline__ void small_load_fast(const double* __restrict__ X, int64_t ld, int r0, int kc, int npieces, int tid,
+                                                int quarter, d2_t (&v)[16]) {
+  const double* ptr = KC ? X + (int64_t)(r0 + (tid >> 3)) * ld + kc + 2 * (tid & 7) : X + (int64_t)(kc + (tid >> 4)) * ld + r0 + 2 * (tid & 15);
+  const int64_t sq = KC ? 16 : 16 * ld;
+#pragma unroll
+  for (int qq = 0; qq < 4; ++qq) {
+    const int q = 4 * quarter + qq;
+    v[q] = q < npieces ? *(const d2_t*)(ptr + q * sq) : (d2_t){0.0, 0.0};
+  }
+}
+
+template <bool KC>
+__device__ __forceinline__ void small_fix(const double* __restrict__ X, int64_t ld, int r0, int R, int kc, int kend, int tid,
+                                          bool vec_ok, bool tri, bool keep_ge, bool unit, int quarter, d2_t (&v)[16]) {
+#pragma unroll
+  for (int qq = 0; qq < 4; ++qq) {
+    const int q = 4 * quarter + qq;
+    int r[2], k[2];
+    if (KC) { r[0] = r[1] = r0 + (tid >> 3); k[0] = kc + 2 * (tid & 7) + 16 * q; k[1] = k[0] + 1; }
+    else { r[0] = r0 + 2 * (tid & 15); r[1] = r[0] + 1; k[0] = k[1] = kc + (tid >> 4) + 16 * q; }
+    const bool in = r[1] < R && k[1] < kend && vec_ok;
+    d2_t val = v[q];
+    if (!in) {                                             // ragged edge / unaligned operand: scalar reads
+      const double* ptr = KC ? X + (int64_t)r[0] * ld + k[0] : X + (int64_t)k[0] * ld + r[0];
+      val = (d2_t){0.0, 0.0};
       if (r[0] < R && k[0] < kend) val.x = ptr[0];
       if (r[1] < R && k[1] < kend) val.y = ptr[1];
     }
@@ -650,16 +682,32 @@ __global__ __launch_bounds__(256, 1) void dgemm_small_kernel(const GemmArgs pin)
   d4_t acc = {0.0, 0.0, 0.0, 0.0};
   for (int kc = klo; kc < khi; kc += SKC) {
     d2_t va[16], vb[16];
+    // interior chunk (the recursion's case): straight-line loads; ragged or unaligned: clamped addresses + fix-ups
+    const int span = khi - kc < SKC ? khi - kc : SKC;
+    const bool fast = p.a_vec && p.b_vec && i0 + ST <= p.M && j0 + ST <= p.N && (span & 15) == 0;
+    if (fast) {
 #pragma unroll
-    for (int quarter = 0; quarter < 4; ++quarter) {        // issue order = consumption order (vmcnt counts in order)
-      small_load<AK>(p.A, p.lda, i0, p.M, kc, khi, tid, p.a_vec, p.tri_side == CAPI_LEFT, keep_ge, p.tri_unit, quarter, va);
-      small_load<BKC>(p.B, p.ldb, j0, p.N, kc, khi, tid, p.b_vec, p.tri_side == CAPI_RIGHT, keep_ge, p.tri_unit, quarter, vb);
+      for (int quarter = 0; quarter < 4; ++quarter) {      // issue order = consumption order (vmcnt counts in order)
+        small_load_fast<AK>(p.A, p.lda, i0, kc, span >> 4, tid, quarter, va);
+        small_load_fast<BKC>(p.B, p.ldb, j0, kc, span >> 4, tid, quarter, vb);
+      }
+    } else {
+#pragma unroll
+      for (int quarter = 0; quarter < 4; ++quarter) {
+        small_load<AK>(p.A, p.lda, i0, p.M, kc, khi, tid, p.a_vec, quarter, va);
+        small_load<BKC>(p.B, p.ldb, j0, p.N, kc, khi, tid, p.b_vec, quarter, vb);
+      }
     }
     if (kc > klo) __syncthreads();                         // the previous chunk's fragments have been consumed
     const int nq = min(4, (khi - kc + SQK - 1) / SQK);
 #pragma unroll
     for (int quarter = 0; quarter < 4; ++quarter) {
       if (quarter >= nq) break;
+      if (!fast || p.tri_side >= 0) {
+        // (on the fast path vec_ok = true and full ranges make every piece "in": only the triangle mask acts)
+        small_fix<AK>(p.A, p.lda, i0, fast ? i0 + ST : p.M, kc, fast ? kc + SKC : khi, tid, p.a_vec, p.tri_side == CAPI_LEFT, keep_ge, p.tri_unit, quarter, va);
+        small_fix<BKC>(p.B, p.ldb, j0, fast ? j0 + ST : p.N, kc, fast ? kc + SKC : khi, tid, p.b_vec, p.tri_side == CAPI_RIGHT, keep_ge, p.tri_unit, quarter, vb);
+      }
       small_store<AK>(La, tid, quarter, va);
       small_store<BKC>(Lb, tid, quarter, vb);
       __syncthreads();

@@ -626,7 +626,10 @@ __device__ __forceinline__ void small_fix(const double* __restrict__ X, int64_t 
       if (r[0] < R && k[0] < kend) val.x = ptr[0];
       if (r[1] < R && k[1] < kend) val.y = ptr[1];
     }
-    if (tri) {
+    // only the pieces whose 16 k's overlap the tile's own 32 rows can straddle the diagonal (the tile's k-range was cut at
+    // the triangle's edge by the caller); the test is uniform per piece
+    const int kq = kc + 16 * q;
+    if (tri && kq < r0 + ST && kq + 16 > r0) {
       if (keep_ge ? (k[0] < r[0]) : (k[0] > r[0])) val.x = 0.0;
       if (keep_ge ? (k[1] < r[1]) : (k[1] > r[1])) val.y = 0.0;
       if (unit) {

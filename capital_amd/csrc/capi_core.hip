@@ -18,7 +18,11 @@ static int capi_create_common(capi_handle_t* out, int device, void* stream, bool
   h->device = device;
   CAPI_HIP_CHECK(h, hipSetDevice(device));
   if (own) {
-    CAPI_HIP_CHECK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    // the handle's own compute stream carries the factorisation's latency-bound chain: highest priority, so that its
+    // workgroups are preferred over the bulk streams' wherever the dispatcher arbitrates
+    int least = 0, greatest = 0;
+    CAPI_HIP_CHECK(h, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    CAPI_HIP_CHECK(h, hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, getenv("CAPI_MAIN_PRIO_NORMAL") ? 0 : greatest));
     h->owns_stream = true;
   } else {
     h->stream = (hipStream_t)stream;
@@ -42,11 +46,14 @@ int capi_destroy(capi_handle_t h) {
   if (!h) return CAPI_EINVAL;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
-  if (h->streams[1]) { (void)hipStreamSynchronize(h->streams[1]); (void)hipStreamDestroy(h->streams[1]); }
+  for (int i = 1; i < capi_handle_s::NSTREAMS; ++i)
+    if (h->streams[i]) { (void)hipStreamSynchronize(h->streams[i]); (void)hipStreamDestroy(h->streams[i]); }
   if (h->streams[0]) h->stream = h->streams[0];
   if (h->events) { for (int i = 0; i < 1024; ++i) if (h->events[i]) (void)hipEventDestroy(h->events[i]); free(h->events); }
-  if (h->ws) (void)hipFree(h->ws);
-  if (h->ws2) (void)hipFree(h->ws2);
+  for (int i = 0; i < capi_handle_s::NSTREAMS; ++i) {
+    if (h->ws[i]) (void)hipFree(h->ws[i]);
+    if (h->ws2[i]) (void)hipFree(h->ws2[i]);
+  }
   if (h->d_info) (void)hipFree(h->d_info);
   if (h->h_info) (void)hipHostFree(h->h_info);
   for (int i = 0; i < h->prof_cap; ++i) if (h->prof[i].e0) { (void)hipEventDestroy(h->prof[i].e0); (void)hipEventDestroy(h->prof[i].e1); }
@@ -99,8 +106,8 @@ int capi_memcpy_d2d_async(capi_handle_t h, void* d, const void* s, size_t bytes)
 }
 int capi_sync(capi_handle_t h) {
   CAPI_REQUIRE(h, h, "null handle");
-  if (h->streams[1]) CAPI_HIP_CHECK(h, hipStreamSynchronize(h->streams[1]));
-  if (h->streams[0]) CAPI_HIP_CHECK(h, hipStreamSynchronize(h->streams[0]));
+  for (int i = capi_handle_s::NSTREAMS - 1; i >= 0; --i)
+    if (h->streams[i]) CAPI_HIP_CHECK(h, hipStreamSynchronize(h->streams[i]));
   CAPI_HIP_CHECK(h, hipStreamSynchronize(h->stream));
   return CAPI_OK;
 }
@@ -124,13 +131,34 @@ int capi_reset_info(capi_handle_t h) {
 }
 
 int capi_stream_select(capi_handle_t h, int which) {
-  CAPI_REQUIRE(h, h && (which == 0 || which == 1), "stream index");
+  CAPI_REQUIRE(h, h && which >= 0 && which < capi_handle_s::NSTREAMS, "stream index");
   if (!h->streams[0]) h->streams[0] = h->stream;
-  if (which == 1 && !h->streams[1]) {
+  if (which >= 1 && !h->streams[which]) {
     CAPI_HIP_CHECK(h, hipSetDevice(h->device));
-    CAPI_HIP_CHECK(h, hipStreamCreateWithFlags(&h->streams[1], hipStreamNonBlocking));
+    if (which == 1) {
+      CAPI_HIP_CHECK(h, hipStreamCreateWithFlags(&h->streams[1], hipStreamNonBlocking));
+    } else {
+      // Bulk streams run long MFMA tile kernels beside the compute stream's latency-bound chain: lowest priority.
+      // A tile workgroup owns a whole CU (512 threads x 256 VGPRs) and the workgroups of one launch finish in rounds, so
+      // the chain's kernels mostly start when a round ends.  CAPITAL_BULK_CUS = n (< number of CUs) instead keeps the
+      // bulk streams off the last CUs with a CU mask (mask bit b = CU b/8 of XCD b%8); measured at n = 32768: the chain
+      // then runs freely, but the bulk launches lose their fit to 256 CUs (8 rounds become 9.1 -> 10) and the step time is
+      // the same, so the default is no mask.
+      const char* e = getenv("CAPITAL_BULK_CUS");
+      int bulk = e ? atoi(e) : 0;
+      if (bulk > 0 && bulk < h->num_cu) {
+        uint32_t mask[16] = {0};
+        for (int b = 0; b < bulk && b < 512; ++b) mask[b >> 5] |= 1u << (b & 31);
+        CAPI_HIP_CHECK(h, hipExtStreamCreateWithCUMask(&h->streams[which], (uint32_t)((h->num_cu + 31) / 32), mask));
+      } else {
+        int least = 0, greatest = 0;
+        CAPI_HIP_CHECK(h, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        CAPI_HIP_CHECK(h, hipStreamCreateWithPriority(&h->streams[which], hipStreamNonBlocking, least));
+      }
+    }
   }
   h->stream = h->streams[which];
+  h->cur = which;
   return CAPI_OK;
 }
 static int event_slot(capi_handle_t h, int slot, hipEvent_t** ev) {
@@ -190,5 +218,5 @@ static int ws_grow(capi_handle_t h, void** slot, size_t* cap, size_t bytes, void
   *p = *slot;
   return CAPI_OK;
 }
-int capi_ws_get(capi_handle_t h, size_t bytes, void** p) { return ws_grow(h, &h->ws, &h->ws_bytes, bytes, p); }
-int capi_ws2_get(capi_handle_t h, size_t bytes, void** p) { return ws_grow(h, &h->ws2, &h->ws2_bytes, bytes, p); }
+int capi_ws_get(capi_handle_t h, size_t bytes, void** p) { return h ? ws_grow(h, &h->ws[h->cur], &h->ws_bytes[h->cur], bytes, p) : CAPI_EINVAL; }
+int capi_ws2_get(capi_handle_t h, size_t bytes, void** p) { return h ? ws_grow(h, &h->ws2[h->cur], &h->ws2_bytes[h->cur], bytes, p) : CAPI_EINVAL; }

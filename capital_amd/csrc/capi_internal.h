@@ -10,15 +10,19 @@ struct capi_handle_s {
   int device = 0;
   hipStream_t stream = nullptr;
   bool owns_stream = false;
-  // stream[0] = compute (== the handle's primary stream), stream[1] = communication, created on first select
-  hipStream_t streams[2] = {nullptr, nullptr};
+  // streams[0] = compute (== the handle's primary stream), streams[1] = communication / packing, streams[2..] = bulk
+  // trailing updates that run beside the factorisation's latency-bound chain (lowest priority); created on first select
+  static constexpr int NSTREAMS = 4;
+  hipStream_t streams[NSTREAMS] = {nullptr, nullptr, nullptr, nullptr};
+  int cur = 0;                    // index of the selected stream
   hipEvent_t* events = nullptr;   // 1024 lazily created slots
-  // private workspace (in-place trmm staging, split-K slabs, potrf panels); grows on demand
-  void* ws = nullptr;
-  size_t ws_bytes = 0;
+  // private workspace (in-place trmm staging, split-K slabs, potrf panels); grows on demand.  One per stream index:
+  // reuse is stream-ordered, so work on different streams must not share a block
+  void* ws[NSTREAMS] = {nullptr, nullptr, nullptr, nullptr};
+  size_t ws_bytes[NSTREAMS] = {0, 0, 0, 0};
   // second, independent scratch block (diagonal-block inverses, recursion temporaries)
-  void* ws2 = nullptr;
-  size_t ws2_bytes = 0;
+  void* ws2[NSTREAMS] = {nullptr, nullptr, nullptr, nullptr};
+  size_t ws2_bytes[NSTREAMS] = {0, 0, 0, 0};
   // device-side LAPACK info word (0 ok, >0 first bad pivot, 1-based) + pinned host mirror
   int* d_info = nullptr;
   int* h_info = nullptr;

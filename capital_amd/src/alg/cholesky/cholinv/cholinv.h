@@ -57,6 +57,8 @@ public:
     // top-level overlap state: the input's right part is copied, and the finished left part packed, on the second stream
     const double* input = nullptr;
     DimensionType early_split = 0;
+    // trailing updates currently running beside the recursion on the bulk streams (single-GPU lookahead)
+    int la_depth = 0;
   };
 
   template <typename MatrixType, typename ArgType, typename CommType>
@@ -124,9 +126,11 @@ public:
     const bool single = (CommInfo.d == 1 && CommInfo.c == 1);
     const U h = localDimension - (localDimension >> args.split);
     const U agg = args.bcDimension;
-    int64_t need = single ? (int64_t)h * h + 64 : (int64_t)8 * h * h + 4 * (int64_t)agg * agg + 1024;
+    // (single GPU: the R12 copies of nested levels stay live while their trailing updates run beside the recursion: h^2 (1 + 1/4 + ...))
+    int64_t need = single ? (int64_t)h * h + (int64_t)h * h / 3 + 1024 : (int64_t)8 * h * h + 4 * (int64_t)agg * agg + 1024;
     args.work.reserve(need);
 
+    args.la_depth = 0;
     invoke(args, CommInfo, R, Ri, ld, (U)0, localDimension, globalDimension);
 
     if (packed) {
@@ -158,6 +162,16 @@ public:
 private:
   // event slots of the top-level overlap (matmult::summa's pipe uses slots below 1000)
   static constexpr int EV_INPUT_HEAD = 1020, EV_INPUT_REST = 1021, EV_TOP_R12 = 1022, EV_EARLY_PACK = 1023;
+  // lookahead (single GPU): slot + depth; the bulk streams are stream indices LA_STREAM0 + depth
+  static constexpr int EV_LA_LEAD = 1010, EV_LA_REST = 1014, LA_STREAM0 = 2, LA_MAX_DEPTH = 2;
+  static int64_t lookahead_min() {
+    static const int64_t v = [] {
+      if (getenv("CAPITAL_NO_LOOKAHEAD")) return (int64_t)-1;
+      const char* e = getenv("CAPITAL_LOOKAHEAD_MIN");
+      return e ? (int64_t)atoll(e) : (int64_t)2048;
+    }();
+    return v;
+  }
 
   // columns [x0,x1), rows [y0,y1) of a full local image into the packed (uppertri) factor; shape = what is copied per column
   template <typename ArgType>
@@ -176,11 +190,12 @@ private:
   }
 
   template <typename ArgType, typename CommType, typename U>
-  static void invoke(ArgType& args, CommType&& t, double* R, double* Ri, U ld, U start, U localDim, U globalDim) {
+  static void invoke(ArgType& args, CommType&& t, double* R, double* Ri, U ld, U start, U localDim, U globalDim, int wait_ev = -1) {
     using matmult::view;
     capi_handle_t h = capital::handle();
     const U split1 = localDim >> args.split;
     if (((localDim * (U)t.d) <= args.bcDimension) || (split1 < args.split)) {     // cholinv.hpp:93
+      if (wait_ev >= 0) CAPITAL_CHECK(capi_event_wait(h, wait_ev));
       CRITTER_START(CI::factor_diag);
       base_case(args, t, R, Ri, ld, start, localDim);
       CRITTER_STOP(CI::factor_diag);
@@ -198,12 +213,15 @@ private:
     view I12{Ri + start + (start + split1) * ld, ld, split1, split2};
 
     invoke(args, t, R, Ri, ld, start, split1, globalDim >> 1);                          // 1
+    // everything of this block beyond its leading part was updated by the parent on a bulk stream: join it here
+    if (wait_ev >= 0) CAPITAL_CHECK(capi_event_wait(h, wait_ev));
 
     const bool top = (localDim == args.localDimension) && args.early_split == split1;
     if (top) CAPITAL_CHECK(capi_event_wait(h, EV_INPUT_REST));                          // the input's right part has landed
     CRITTER_START(CI::trsm);                                                            // 2
+    int child_wait = -1;
+    const int64_t mark = ws.top;
     {
-      const int64_t mark = ws.top;
       view W{ws.take((int64_t)split1 * split2), split1, split1, split2};
       if (single) {
         CAPITAL_CHECK(capi_dtrmm_oop(h, CAPI_LEFT, CAPI_UPPER, CAPI_TRANS, CAPI_NONUNIT, split1, split2, 1.0, R11i.p, ld, A12.p, ld, W.p, W.ld));
@@ -241,7 +259,27 @@ private:
       }
 
       CRITTER_START(CI::tmu);                                                           // 3
-      if (single) {
+      // Lookahead: the trailing block's recursion starts with a long chain of latency-bound kernels on its leading
+      // part, which needs only that part updated.  Update it first; the rest of the update runs on a low-priority
+      // bulk stream beside that chain and is joined before the trailing block's own R12 product.
+      const U lead = split2 >> args.split;
+      const bool a22_splits = !(((split2 * (U)t.d) <= args.bcDimension) || (lead < args.split));
+      if (single && a22_splits && lead > 0 && lookahead_min() >= 0 && (int64_t)split2 >= lookahead_min() && args.la_depth < LA_MAX_DEPTH) {
+        const int depth = args.la_depth;
+        const U rest = split2 - lead;
+        double* Wr = W.p + (int64_t)lead * W.ld;
+        CAPITAL_CHECK(capi_dgemmt(h, CAPI_UPPER, CAPI_TRANS, CAPI_NOTRANS, lead, split1, -1.0, W.p, W.ld, W.p, W.ld, 1.0, A22.p, ld));
+        CAPITAL_CHECK(capi_event_record(h, EV_LA_LEAD + depth));
+        CAPITAL_CHECK(capi_stream_select(h, LA_STREAM0 + depth));
+        CAPITAL_CHECK(capi_event_wait(h, EV_LA_LEAD + depth));
+        CAPITAL_CHECK(capi_dgemm(h, CAPI_TRANS, CAPI_NOTRANS, lead, rest, split1, -1.0, W.p, W.ld, Wr, W.ld, 1.0, A22.p + (int64_t)lead * ld, ld));
+        CAPITAL_CHECK(capi_dgemmt(h, CAPI_UPPER, CAPI_TRANS, CAPI_NOTRANS, rest, split1, -1.0, Wr, W.ld, Wr, W.ld, 1.0,
+                                  A22.p + lead + (int64_t)lead * ld, ld));
+        CAPITAL_CHECK(capi_event_record(h, EV_LA_REST + depth));
+        CAPITAL_CHECK(capi_stream_select(h, 0));
+        child_wait = EV_LA_REST + depth;
+        ++args.la_depth;                  // W stays allocated until the trailing block's recursion has joined
+      } else if (single) {
         CAPITAL_CHECK(capi_dgemmt(h, CAPI_UPPER, CAPI_TRANS, CAPI_NOTRANS, split2, split1, -1.0, W.p, W.ld, W.p, W.ld, 1.0, A22.p, ld));
       } else {
         view Wx{ws.take(W.count()), split1, split1, split2};
@@ -249,11 +287,12 @@ private:
         util::transpose_raw(Wx.p, Wx.count(), ws.take(Wx.count()), t);
         matmult::summa::syrk(t, CAPI_UPPER, CAPI_TRANS, -1.0, W, Wx, 1.0, A22, ws);
       }
-      ws.top = mark;
+      if (child_wait < 0) ws.top = mark;
       CRITTER_STOP(CI::tmu);
     }
 
-    invoke(args, t, R, Ri, ld, start + split1, split2, split2 * (U)t.d);                // 4
+    invoke(args, t, R, Ri, ld, start + split1, split2, split2 * (U)t.d, child_wait);    // 4
+    if (child_wait >= 0) { --args.la_depth; ws.top = mark; }
 
     CRITTER_START(CI::tmu);                                                             // 5
     if (!(!args.complete_inv && (globalDim == args.trueGlobalDimension))) {

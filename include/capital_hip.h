@@ -161,10 +161,11 @@ int capi_reduce_sum(capi_comm_t c, const double* send, double* recv, int64_t cou
 int capi_allgather(capi_comm_t c, const double* send, double* recv, int64_t count_per_rank);   /* MPI_Allgather, policy.h:176 */
 int capi_sendrecv_replace(capi_comm_t c, double* buf, int64_t count, int peer, double* staging); /* MPI_Sendrecv_replace, util.hpp:240 */
 
-/* ---- second stream + events: lets the host layer run collectives beside the tile kernel (the reference's
- *      MPI_Ibcast/Iallreduce chunk pipeline, summa.hpp:195-215,238-249).  capi_stream_select(h, 1) routes every
- *      following call on this handle (kernels, copies, collectives) to the handle's communication stream, 0 back to
- *      the compute stream; events order work across the two (slot in [0, 1024)). ---- */
+/* ---- extra streams + events: lets the host layer run collectives beside the tile kernel (the reference's
+ *      MPI_Ibcast/Iallreduce chunk pipeline, summa.hpp:195-215,238-249) and the bulk of a trailing update beside the
+ *      next block's factorisation.  capi_stream_select(h, i) routes every following call on this handle (kernels,
+ *      copies, collectives) to stream i: 0 = compute stream, 1 = communication / packing stream, 2..3 = low-priority bulk
+ *      streams.  Each stream index has its own private workspace; events order work across streams (slot in [0, 1024)). ---- */
 int capi_stream_select(capi_handle_t h, int which);
 int capi_event_record(capi_handle_t h, int slot);   /* on the currently selected stream */
 int capi_event_wait(capi_handle_t h, int slot);     /* the currently selected stream waits for that record */

@@ -87,6 +87,9 @@ def main():
     ap.add_argument("--no-qr", action="store_true")
     args = ap.parse_args()
 
+    # a hung collective must end the run with a traceback, not sit on the node until the driver's limit
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get("CAPITAL_BENCH_WATCHDOG_S", "1500")), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -186,6 +189,7 @@ def main():
         L.capi_mfma_f64_peak(h, 20000, C.byref(peak))
         out["mfma_f64_loop_tflops"] = peak.value
         print(json.dumps(out), flush=True)
+    faulthandler.cancel_dump_traceback_later()
     driver.finalize()
     if distributed:
         dist.destroy_process_group()

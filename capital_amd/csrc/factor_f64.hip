@@ -206,11 +206,28 @@ __device__ __forceinline__ void leaf_store_upper(const double* __restrict__ M, d
   }
 }
 
+// side job of a leaf launch: workgroups 1.. copy a rows x cols block (the row panel right of the diagonal block) into a
+// compact buffer while workgroup 0 factors -- the panel product that follows then writes R12 straight into place
+struct LeafCopy {
+  const double* src;
+  double* dst;
+  int64_t lds, ldd, cols;
+  int rows;
+};
+
 __global__ __launch_bounds__(LEAF_THREADS, 1) void potrf_trtri_leaf128_kernel(double* __restrict__ A, int64_t lda, double* __restrict__ X,
                                                                       int64_t ldx, int b, int want_inv, int zero_lower,
                                                                       int invert_only, int unit, int* __restrict__ info,
-                                                                      int info_base, long long* __restrict__ dbg) {
+                                                                      int info_base, long long* __restrict__ dbg, LeafCopy cp) {
   extern __shared__ __attribute__((aligned(16))) double lds_leaf[];
+  if (blockIdx.x > 0) {
+    const int r = threadIdx.x & (LEAF - 1), c0 = threadIdx.x / LEAF;
+    constexpr int CPW = LEAF_THREADS / LEAF;      // columns per pass
+    if (r < cp.rows)
+      for (int64_t c = (int64_t)(blockIdx.x - 1) * CPW + c0; c < cp.cols; c += (int64_t)(gridDim.x - 1) * CPW)
+        cp.dst[r + c * cp.ldd] = cp.src[r + c * cp.lds];
+    return;
+  }
   int dbg_n = 0;
 #define LEAF_MARK() do { if (dbg && threadIdx.x == 0) dbg[dbg_n++] = clock64(); } while (0)
   LEAF_MARK();
@@ -463,8 +480,15 @@ int64_t split_point(int64_t n) {
 }
 
 int leaf_launch(capi_handle_t h, double* A, int64_t lda, double* X, int64_t ldx, int b, int want_inv, int zero_lower,
-                int invert_only, int unit, int info_base) {
+                int invert_only, int unit, int info_base, const LeafCopy* side = nullptr) {
   {
+    LeafCopy cp{nullptr, nullptr, 0, 0, 0, 0};
+    unsigned blocks = 1;
+    if (side && side->cols > 0 && side->rows > 0) {
+      cp = *side;
+      const int64_t want = cdiv(cp.cols, 32);       // >= 8 passes of LEAF_THREADS / LEAF columns per workgroup
+      blocks += (unsigned)(want < 192 ? want : 192);
+    }
     const size_t lds_bytes = sizeof(double) * (LB * LLD + LNT * 256 + 4 * 16);
     static bool attr_set = false;
     if (!attr_set) {
@@ -474,8 +498,8 @@ int leaf_launch(capi_handle_t h, double* A, int64_t lda, double* X, int64_t ldx,
     static const bool trace = getenv("CAPI_LEAF_TRACE") != nullptr;
     long long* dbg = nullptr;
     if (trace) CAPI_HIP_CHECK(h, hipMalloc((void**)&dbg, sizeof(long long) * 64));
-    hipLaunchKernelGGL(potrf_trtri_leaf128_kernel, dim3(1), dim3(LEAF_THREADS), lds_bytes, h->stream, A, lda, X, ldx, b, want_inv, zero_lower,
-                       invert_only, unit, h->d_info, info_base, dbg);
+    hipLaunchKernelGGL(potrf_trtri_leaf128_kernel, dim3(blocks), dim3(LEAF_THREADS), lds_bytes, h->stream, A, lda, X, ldx, b, want_inv, zero_lower,
+                       invert_only, unit, h->d_info, info_base, dbg, cp);
     if (trace) {   // diagnostics only: phase timestamps (shader clock) of this launch
       long long t[64];
       CAPI_HIP_CHECK(h, hipStreamSynchronize(h->stream));
@@ -540,12 +564,14 @@ int potrf_trtri_blocked(capi_handle_t h, int64_t n, double* A, int64_t lda, doub
     const int64_t j0 = j * LEAF, jb = (n - j0) < LEAF ? (n - j0) : LEAF, rest = n - j0 - jb;
     double* Ajj = A + j0 + j0 * lda;
     double* Xjj = X + j0 + j0 * ldx;
-    RC(leaf_launch(h, Ajj, lda, Xjj, ldx, (int)jb, 1, 0, 0, 0, info_base + (int)j0));
+    double* Ajr = A + j0 + (j0 + jb) * lda;
+    // the row panel is copied aside by spare workgroups of the diagonal block's launch; the panel product then reads the
+    // copy and writes R12 in place (no copy kernel on the critical chain)
+    const LeafCopy side{Ajr, W, lda, jb, rest, (int)jb};
+    RC(leaf_launch(h, Ajj, lda, Xjj, ldx, (int)jb, 1, 0, 0, 0, info_base + (int)j0, &side));
     if (rest > 0) {
-      double* Ajr = A + j0 + (j0 + jb) * lda;
-      RC(capi_dtrmm_oop(h, CAPI_LEFT, CAPI_UPPER, CAPI_TRANS, CAPI_NONUNIT, jb, rest, 1.0, Xjj, ldx, Ajr, lda, W, jb));
-      RC(capi_dlacpy(h, 0, jb, rest, W, jb, Ajr, lda));
-      RC(capi_dgemmt(h, CAPI_UPPER, CAPI_TRANS, CAPI_NOTRANS, rest, jb, -1.0, W, jb, W, jb, 1.0, A + (j0 + jb) + (j0 + jb) * lda, lda));
+      RC(capi_dtrmm_oop(h, CAPI_LEFT, CAPI_UPPER, CAPI_TRANS, CAPI_NONUNIT, jb, rest, 1.0, Xjj, ldx, W, jb, Ajr, lda));
+      RC(capi_dgemmt(h, CAPI_UPPER, CAPI_TRANS, CAPI_NOTRANS, rest, jb, -1.0, Ajr, lda, Ajr, lda, 1.0, A + (j0 + jb) + (j0 + jb) * lda, lda));
     }
   }
   double* T = W + (int64_t)LEAF * n;

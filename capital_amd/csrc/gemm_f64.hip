@@ -931,39 +931,51 @@ __device__ __forceinline__ void trmm_ts_body(const GemmArgs& p, double* __restri
 #pragma unroll
   for (int s_ = 0; s_ < NB; ++s_) tb[s_] = tget(4 * s_ + g, 16 * SB + r16);
 
-  // A tile -> registers: thread t owns k = t >> 1 and rows 8 (t & 1) .. +7 (64 contiguous bytes)
-  const int lk = tid >> 1, lh = tid & 1;
+  // A tile -> registers: thread t owns rows 2 (t & 7), +1 of columns (t >> 3) + 64 q: the 8 lanes of a group fetch one
+  // whole 128-byte line (the tile's 16 rows of one column), a wave instruction 8 whole lines.  (A first mapping gave each
+  // thread 64 contiguous bytes: every instruction then touched 32 lines, 32 bytes of each, four times over.)
+  const int lc = tid >> 3, lr = 2 * (tid & 7);
   auto load = [&](int tile, d2_t (&st)[4]) {
-    const int row0 = 16 * tile + 8 * lh;
-    const bool in = row0 + 8 <= p.M && p.a_vec;
-    const double* src = in ? p.A + row0 + (int64_t)lk * p.lda : p.A;
+    const bool in = 16 * tile + 16 <= p.M && p.a_vec;
+    const double* src = in ? p.A + 16 * tile + lr + (int64_t)lc * p.lda : p.A;
+    const int64_t cs = in ? 64 * p.lda : 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) st[q] = *(const d2_t*)(src + 2 * q);
+    for (int q = 0; q < 4; ++q) st[q] = *(const d2_t*)(src + q * cs);
   };
   auto stage = [&](double* L, int tile, const d2_t (&st)[4]) {
     // workgroup-uniform fast path: no branch (and so no conservative s_waitcnt vmcnt(0) at a join) around the LDS stores
     if (p.a_vec && 16 * tile + 16 <= p.M) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) *(d2_t*)&L[lk * 16 + 8 * lh + 2 * q] = st[q];
+      for (int q = 0; q < 4; ++q) *(d2_t*)&L[(lc + 64 * q) * 16 + lr] = st[q];
       return;
     }
-    const int row0 = 16 * tile + 8 * lh;
+    const int r = 16 * tile + lr;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {                           // ragged last tile / unaligned A: scalar reads
-      const int r = row0 + 2 * q;
+      const int64_t c = lc + 64 * q;
       d2_t v = {0.0, 0.0};
-      if (r < p.M) v.x = p.A[r + (int64_t)lk * p.lda];
-      if (r + 1 < p.M) v.y = p.A[r + 1 + (int64_t)lk * p.lda];
-      *(d2_t*)&L[lk * 16 + 8 * lh + 2 * q] = v;
+      if (r < p.M) v.x = p.A[r + c * p.lda];
+      if (r + 1 < p.M) v.y = p.A[r + 1 + c * p.lda];
+      *(d2_t*)&L[c * 16 + lr] = v;
     }
   };
   const int t0 = blockIdx.x, dt = gridDim.x;
   if (t0 >= ntile) return;
   d2_t stA[4], stB[4];
   int par = 0;
-  auto step = [&](int tile, d2_t (&cur)[4], d2_t (&nw)[4]) {   // cur holds tile + dt, nw receives tile + 2 dt
+  // STEADY: the two tiles ahead exist and are full, A is 16-byte aligned and beta == 0 -- the iteration then has no branch
+  // at all.  That matters beyond the branch itself: a load or store inside a branch makes the compiler wait with
+  // s_waitcnt vmcnt(0) at the next use of ANY loaded value, i.e. each staging waited for the prefetch issued 68 MFMAs
+  // earlier AND for the previous tile's eight stores (measured: stores 1.8 ms, loads 1.3 ms of a 6.3 ms kernel whose
+  // MFMAs take 4.1 ms).  Straight-line, the wait before staging is vmcnt(12): stores and the newest prefetch stay in flight.
+  auto step = [&](int tile, d2_t (&cur)[4], d2_t (&nw)[4], auto steady_tag) {   // cur holds tile + dt, nw receives tile + 2 dt
+    constexpr bool STEADY = decltype(steady_tag)::value;
     const double* L = lds + par * TILE;
-    if (tile + 2 * dt < ntile) load(tile + 2 * dt, nw);
+    if (STEADY) {
+      const double* src = p.A + 16 * (tile + 2 * dt) + lr + (int64_t)lc * p.lda;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) nw[q] = *(const d2_t*)(src + q * 64 * p.lda);
+    } else if (tile + 2 * dt < ntile) load(tile + 2 * dt, nw);
     d4_t ca = {0.0, 0.0, 0.0, 0.0}, cb = {0.0, 0.0, 0.0, 0.0};
     const double* la = L + g * 16 + r16;                    // A[row r16][k = 4 s + g]
     __builtin_amdgcn_s_setprio(1);
@@ -974,18 +986,22 @@ __device__ __forceinline__ void trmm_ts_body(const GemmArgs& p, double* __restri
       cb = __builtin_amdgcn_mfma_f64_16x16x4f64(tb[s_], af, cb, 0, 0, 0);
     }
     __builtin_amdgcn_s_setprio(0);
-    if (tile + dt < ntile) stage(lds + (par ^ 1) * TILE, tile + dt, cur);
+    if (STEADY) {
+      double* Ln = lds + (par ^ 1) * TILE;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *(d2_t*)&Ln[(lc + 64 * q) * 16 + lr] = cur[q];
+    } else if (tile + dt < ntile) stage(lds + (par ^ 1) * TILE, tile + dt, cur);
     par ^= 1;
     __syncthreads();
     // lane holds (i = row r16 of the tile, j = 16 strip + g + 4 reg): 16 lanes -> 128 contiguous bytes of one column
     // (beta is tested ONCE: a per-store `if (beta != 0) r += beta * *c` puts a load in a branch before every store, and
     //  the compiler then parks an s_waitcnt vmcnt(0) at each join -- eight full drains of the prefetch queue per tile)
     const int i = 16 * tile + r16;
-    if (i < p.M) {
+    if (STEADY || i < p.M) {
       double* c0_ = p.C + i + (int64_t)(16 * SA + g) * p.ldc;
       double* c1_ = p.C + i + (int64_t)(16 * SB + g) * p.ldc;
       const int64_t s4 = 4 * p.ldc;
-      if (p.beta == 0.0) {
+      if (STEADY || p.beta == 0.0) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) { c0_[reg * s4] = p.alpha * ca[reg]; c1_[reg * s4] = p.alpha * cb[reg]; }
       } else {
@@ -1001,9 +1017,157 @@ __device__ __forceinline__ void trmm_ts_body(const GemmArgs& p, double* __restri
   if (t0 + dt < ntile) load(t0 + dt, stB);
   stage(lds, t0, stA);
   __syncthreads();
-  for (int tile = t0; tile < ntile; tile += 2 * dt) {
-    step(tile, stB, stA);
-    if (tile + dt < ntile) step(tile + dt, stA, stB);
+  int tile = t0;
+  if (p.a_vec && p.beta == 0.0) {
+    const int nfull = p.M >> 4;                             // tiles with all 16 rows
+    for (; tile + 3 * dt < nfull; tile += 2 * dt) {         // both steps see tile + 2 dt full
+      step(tile, stB, stA, std::true_type{});
+      step(tile + dt, stA, stB, std::true_type{});
+    }
+  }
+  for (; tile < ntile; tile += 2 * dt) {
+    step(tile, stB, stA, std::false_type{});
+    if (tile + dt < ntile) step(tile + dt, stA, stB, std::false_type{});
+  }
+}
+
+// The same T-stationary scheme on 32-row tiles (two 16-row halves, each laid out [k][16 rows] in LDS, 2 x 64 KB): every T
+// fragment feeds two MFMAs, a wave runs four accumulator chains instead of two, there is one barrier per 136 MFMAs, and a
+// tile's 256 bytes of one column (= one address translation; the 256 columns are 256 pages 8 lda bytes apart) are fetched
+// by one 16-lane group.  One tile is in flight in registers (its loads have the 136 MFMAs of the current tile to land).
+template <int W>
+__device__ __forceinline__ void trmm_ts32_body(const GemmArgs& p, double* __restrict__ lds) {
+  constexpr int SA = W, SB = 15 - W, NA = 4 * (SA + 1), NB = 4 * (SB + 1);   // strips and their k-step counts (NA <= NB)
+  constexpr int HALF = 256 * 16, TILE = 2 * HALF;          // LDS tile: [half][k][16 rows]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int ntile = (p.M + 31) >> 5;
+  double ta[NA], tb[NB];
+  auto tget = [&](int k, int j) {
+    double v = p.B[k + (int64_t)j * p.ldb];
+    if (k > j) v = 0.0;
+    if (p.tri_unit && k == j) v = 1.0;
+    return v;
+  };
+#pragma unroll
+  for (int s_ = 0; s_ < NA; ++s_) ta[s_] = tget(4 * s_ + g, 16 * SA + r16);
+#pragma unroll
+  for (int s_ = 0; s_ < NB; ++s_) tb[s_] = tget(4 * s_ + g, 16 * SB + r16);
+
+  // thread t owns rows 2 (t & 15), +1 of columns (t >> 4) + 32 q: 16 lanes fetch the tile's 256 bytes of one column
+  const int lc = tid >> 4, lr = 2 * (tid & 15);
+  const int lofs = (lr >> 4) * HALF + lc * 16 + (lr & 15);  // LDS offset of (rows lr, lr + 1; column lc)
+  auto load = [&](int tile, d2_t (&st)[8]) {
+    const bool in = 32 * tile + 32 <= p.M && p.a_vec;
+    const double* src = in ? p.A + 32 * tile + lr + (int64_t)lc * p.lda : p.A;
+    const int64_t cs = in ? 32 * p.lda : 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) st[q] = *(const d2_t*)(src + q * cs);
+  };
+  auto stage = [&](double* L, int tile, const d2_t (&st)[8]) {
+    if (p.a_vec && 32 * tile + 32 <= p.M) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) *(d2_t*)&L[lofs + 512 * q] = st[q];
+      return;
+    }
+    const int r = 32 * tile + lr;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {                           // ragged last tile / unaligned A: scalar reads
+      const int64_t c = lc + 32 * q;
+      d2_t v = {0.0, 0.0};
+      if (r < p.M) v.x = p.A[r + c * p.lda];
+      if (r + 1 < p.M) v.y = p.A[r + 1 + c * p.lda];
+      *(d2_t*)&L[lofs + 512 * q] = v;
+    }
+  };
+  const int t0 = blockIdx.x, dt = gridDim.x;
+  if (t0 >= ntile) return;
+  d2_t st[8];
+  int par = 0;
+  // STEADY: the next tile exists and is full, A is 16-byte aligned, beta == 0: an iteration without a single branch
+  // (a load or store inside a branch costs an s_waitcnt vmcnt(0) at the next use of any loaded value)
+  auto step = [&](int tile, auto steady_tag) {
+    constexpr bool STEADY = decltype(steady_tag)::value;
+    const double* L = lds + par * TILE;
+    if (STEADY) {
+      const double* src = p.A + 32 * (tile + dt) + lr + (int64_t)lc * p.lda;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) st[q] = *(const d2_t*)(src + q * 32 * p.lda);
+    } else if (tile + dt < ntile) load(tile + dt, st);
+    d4_t ca0 = {0.0, 0.0, 0.0, 0.0}, ca1 = ca0, cb0 = ca0, cb1 = ca0;
+    const double* la = L + g * 16 + r16;                    // A[row r16 (+16)][k = 4 s + g]
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s_ = 0; s_ < NB; ++s_) {
+      const double a0 = la[64 * s_], a1 = la[HALF + 64 * s_];
+      if (s_ < NA) {
+        ca0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[s_], a0, ca0, 0, 0, 0);
+        ca1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[s_], a1, ca1, 0, 0, 0);
+      }
+      cb0 = __builtin_amdgcn_mfma_f64_16x16x4f64(tb[s_], a0, cb0, 0, 0, 0);
+      cb1 = __builtin_amdgcn_mfma_f64_16x16x4f64(tb[s_], a1, cb1, 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if (STEADY) {
+      double* Ln = lds + (par ^ 1) * TILE;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) *(d2_t*)&Ln[lofs + 512 * q] = st[q];
+    } else if (tile + dt < ntile) stage(lds + (par ^ 1) * TILE, tile + dt, st);
+    par ^= 1;
+    __syncthreads();
+    // lane holds (i = row r16 (+16) of the tile, j = 16 strip + g + 4 reg): 16 lanes -> 128 contiguous bytes of one column
+    const int i = 32 * tile + r16;
+    double* c0_ = p.C + i + (int64_t)(16 * SA + g) * p.ldc;
+    double* c1_ = p.C + i + (int64_t)(16 * SB + g) * p.ldc;
+    const int64_t s4 = 4 * p.ldc;
+    if (STEADY) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        c0_[reg * s4] = p.alpha * ca0[reg]; c0_[reg * s4 + 16] = p.alpha * ca1[reg];
+        c1_[reg * s4] = p.alpha * cb0[reg]; c1_[reg * s4 + 16] = p.alpha * cb1[reg];
+      }
+    } else {
+      const bool ok0 = i < p.M, ok1 = i + 16 < p.M;
+      if (p.beta == 0.0) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          if (ok0) { c0_[reg * s4] = p.alpha * ca0[reg]; c1_[reg * s4] = p.alpha * cb0[reg]; }
+          if (ok1) { c0_[reg * s4 + 16] = p.alpha * ca1[reg]; c1_[reg * s4 + 16] = p.alpha * cb1[reg]; }
+        }
+      } else {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          if (ok0) { c0_[reg * s4] = p.alpha * ca0[reg] + p.beta * c0_[reg * s4]; c1_[reg * s4] = p.alpha * cb0[reg] + p.beta * c1_[reg * s4]; }
+          if (ok1) {
+            c0_[reg * s4 + 16] = p.alpha * ca1[reg] + p.beta * c0_[reg * s4 + 16];
+            c1_[reg * s4 + 16] = p.alpha * cb1[reg] + p.beta * c1_[reg * s4 + 16];
+          }
+        }
+      }
+    }
+  };
+  load(t0, st);
+  stage(lds, t0, st);
+  __syncthreads();
+  int tile = t0;
+  if (p.a_vec && p.beta == 0.0) {
+    const int nfull = p.M >> 5;                             // tiles with all 32 rows
+    for (; tile + dt < nfull; tile += dt) step(tile, std::true_type{});
+  }
+  for (; tile < ntile; tile += dt) step(tile, std::false_type{});
+}
+
+__global__ __launch_bounds__(TSK_THREADS, 1) void trmm_right_ts32_kernel(const GemmArgs p) {   // N == K == 256
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
+    case 0: trmm_ts32_body<0>(p, lds); break;
+    case 1: trmm_ts32_body<1>(p, lds); break;
+    case 2: trmm_ts32_body<2>(p, lds); break;
+    case 3: trmm_ts32_body<3>(p, lds); break;
+    case 4: trmm_ts32_body<4>(p, lds); break;
+    case 5: trmm_ts32_body<5>(p, lds); break;
+    case 6: trmm_ts32_body<6>(p, lds); break;
+    default: trmm_ts32_body<7>(p, lds); break;
   }
 }
 
@@ -1051,10 +1215,12 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
         (int64_t)p.M >= 64 * (int64_t)p.N) {
       p.a_vec = (((uintptr_t)p.A & 15) == 0) && ((p.lda & 1) == 0);
       p.splitk = 1;
-      const int ntile = (int)cdiv(p.M, 16);
+      static const bool rows16 = getenv("CAPI_TS_ROWS16") != nullptr;     // the 16-row-tile variant (A/B)
+      const int rows = rows16 ? 16 : 32;
+      const int ntile = (int)cdiv(p.M, rows);
       const int grid = ntile < h->num_cu ? ntile : h->num_cu;
-      const size_t lds_bytes = sizeof(double) * 2 * 256 * 16;
-      void (*k)(const GemmArgs) = trmm_right_ts_kernel;
+      const size_t lds_bytes = sizeof(double) * 2 * 256 * rows;
+      void (*k)(const GemmArgs) = rows16 ? trmm_right_ts_kernel : trmm_right_ts32_kernel;
       static bool attr_set = false;
       if (!attr_set) {
         CAPI_HIP_CHECK(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

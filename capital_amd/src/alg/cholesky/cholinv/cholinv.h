@@ -164,13 +164,12 @@ private:
   static constexpr int EV_INPUT_HEAD = 1020, EV_INPUT_REST = 1021, EV_TOP_R12 = 1022, EV_EARLY_PACK = 1023;
   // lookahead (single GPU): slot + depth; the bulk streams are stream indices LA_STREAM0 + depth
   static constexpr int EV_LA_LEAD = 1010, EV_LA_REST = 1014, LA_STREAM0 = 2, LA_MAX_DEPTH = 2;
+  // smallest trailing block whose update is split (CAPITAL_LOOKAHEAD_MIN, default 2048; CAPITAL_NO_LOOKAHEAD turns it off);
+  // read per call so that tests can exercise the path at small orders
   static int64_t lookahead_min() {
-    static const int64_t v = [] {
-      if (getenv("CAPITAL_NO_LOOKAHEAD")) return (int64_t)-1;
-      const char* e = getenv("CAPITAL_LOOKAHEAD_MIN");
-      return e ? (int64_t)atoll(e) : (int64_t)2048;
-    }();
-    return v;
+    if (getenv("CAPITAL_NO_LOOKAHEAD")) return -1;
+    const char* e = getenv("CAPITAL_LOOKAHEAD_MIN");
+    return e ? (int64_t)atoll(e) : (int64_t)2048;
   }
 
   // columns [x0,x1), rows [y0,y1) of a full local image into the packed (uppertri) factor; shape = what is copied per column

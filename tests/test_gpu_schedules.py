@@ -39,6 +39,31 @@ def test_cholinv_matches_oracle(drv, oracle, n, bc, ci, split, serialize):
     p.close()
 
 
+@pytest.mark.parametrize("n,bc,ci,split", [(1000, -3, 0, 1), (1024, -4, 1, 1), (768, -3, 1, 2), (2048, -5, 0, 1), (4608, -3, 1, 1)])
+def test_cholinv_lookahead_matches_oracle(drv, oracle, monkeypatch, n, bc, ci, split):
+    """single-GPU lookahead (the bulk of each trailing update on a second stream beside the next block's factorisation),
+    forced on at every level that splits; the default threshold (2048) only reaches it at n >= 4096"""
+    monkeypatch.setenv("CAPITAL_LOOKAHEAD_MIN", "64")
+    p = drv.Cholinv(n, c=1, complete_inv=ci, split=split, bc_mult=bc, serialize=True, bc_policy=2)
+    p.generate()
+    A = p.A()
+    p.factor()
+    R, Ri = p.R(), p.Rinv()
+    p.factor()                                           # second call: streams, events and workspaces are reused
+    np.testing.assert_array_equal(R, p.R())
+    monkeypatch.setenv("CAPITAL_NO_LOOKAHEAD", "1")
+    p.factor()
+    R0, Ri0 = p.R(), p.Rinv()
+    Rref, Riref, info = oracle.cholinv_factor(A, ci, split, bc, 1, 1)
+    assert info == 0
+    for got, got0, ref in ((R, R0, Rref), (Ri, Ri0, Riref)):
+        assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
+        assert np.abs(got - got0).max() <= 1e-13 * np.abs(ref).max()
+        assert np.all(np.tril(got, -1) == 0) and np.count_nonzero(got) == np.count_nonzero(ref)
+    assert p.residual() <= 1e-14
+    p.close()
+
+
 def test_cholinv_repeat_is_deterministic(drv, oracle):
     p = drv.Cholinv(768, bc_mult=-2, serialize=False)
     p.generate()

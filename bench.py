@@ -62,18 +62,23 @@ def cpu_baseline(n_sample):
 def recorded_traffic(n, gpus):
     """L2-to-fabric bytes per launch of the roofline kernel from the committed PMC passes (FETCH_SIZE + WRITE_SIZE, x2 on
     gfx950; profiles/README.md).  Counters cannot be read from inside a timed run, so this is the last recorded
-    measurement of the same configuration, or None."""
+    measurement of the same configuration, or None.  The passes ran `bench.py --steps 1 --warmup 0`: every row but the
+    last (the residual check's product) is a launch of the one factor() call."""
     if n != 32768 or gpus != 1:
         return None, None
     import csv
-    tot = 0.0
+    tot, launches = 0.0, 0
     try:
-        for tag, name in (("f", "FETCH_SIZE"), ("w", "WRITE_SIZE")):
-            rows = [r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", f"r1_c_pmc_{tag}_bench_step.csv"))) if r["Counter_Name"] == name]
-            tot += sum(float(r["Counter_Value"]) for r in rows[:18]) * 1024 * 2      # KB, 128-B requests counted at 64 B
+        for tag, name in (("fe", "FETCH_SIZE"), ("wr", "WRITE_SIZE")):
+            rows = [r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", f"r1_d_pmc_{tag}_bench_step.csv"))) if r["Counter_Name"] == name]
+            rows = rows[:-1]
+            launches = len(rows)
+            tot += sum(float(r["Counter_Value"]) for r in rows) * 1024 * 2      # KB, 128-B requests counted at 64 B
     except (OSError, KeyError, ValueError):
         return None, None
-    return tot / 18.0, "profiles/r1_c_pmc_{f,w}_bench_step.csv: FETCH_SIZE+WRITE_SIZE x2, mean of the 18 launches of one factor()"
+    if not launches:
+        return None, None
+    return tot / launches, f"profiles/r1_d_pmc_{{fe,wr}}_bench_step.csv: FETCH_SIZE+WRITE_SIZE x2, mean of the {launches} launches of one factor()"
 
 
 def main():

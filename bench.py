@@ -87,7 +87,9 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=0, help="override the Cholesky order (diagnostics only)")
-    ap.add_argument("--bc", type=int, default=-5, help="bc_mult_dim of cholinv (base-case order = n / 2^|bc|)")
+    ap.add_argument("--bc", type=int, default=None, help="bc_mult_dim of cholinv (base-case order = c*d*n / 2^|bc| ... see cholinv.hpp:15-18); "
+                    "default -5 on one GPU (order 1024), -4 on a grid (aggregated order 1024 as well: every recursion node below "
+                    "that costs ~13 latency-bound collectives)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-qr", action="store_true")
     args = ap.parse_args()
@@ -116,6 +118,8 @@ def main():
 
     if args.gpus not in CHOLESKY_GRID:
         raise SystemExit(f"--gpus must be one of {sorted(CHOLESKY_GRID)} (d*d*c grids of one node)")
+    if args.bc is None:
+        args.bc = -4 if distributed else -5
     n, c = CHOLESKY_GRID[args.gpus]
     if args.n:
         n = args.n

@@ -69,6 +69,7 @@ public:
     if (!(args.split > 0) || args.dir != 'U') throw std::invalid_argument("cholinv: split > 0 and dir == 'U' required (cholinv.hpp:9)");
     if (CommInfo.d > 1 && CommInfo.d % CommInfo.c) throw std::invalid_argument("cholinv: c must divide d (or d == 1)");
     const U localDimension = A.num_rows_local(), globalDimension = A.num_rows_global();
+    CAPITAL_CHECK(capi_stream_select(capital::handle(), 0));    // (a call that threw mid-way may have left another stream selected)
     args.R._register_(A.num_columns_global(), A.num_rows_global(), CommInfo.d, CommInfo.d);
     args.Rinv._register_(A.num_columns_global(), A.num_rows_global(), CommInfo.d, CommInfo.d);
     constexpr bool packed = !std::is_same<typename SP::structure, rect>::value;

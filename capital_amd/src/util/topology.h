@@ -11,6 +11,10 @@
 #ifndef CAPITAL_TOPOLOGY_H_
 #define CAPITAL_TOPOLOGY_H_
 
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
 #include "shared.h"
 
 namespace topo {
@@ -27,7 +31,7 @@ inline size_t isqrt_ceil(size_t v) { size_t r = (size_t)std::llround(std::ceil(s
 
 class square {
 public:
-  // comm: parent communicator (capital::world()); c: replication depth; layout as in the reference (0,1 supported)
+  // comm: parent communicator (capital::world()); c: replication depth; layout as in the reference (0, 1, 2)
   square(capi_comm_t comm, size_t c_, size_t layout_ = 0, size_t num_chunks_ = 0) : c(c_), layout(layout_), num_chunks(num_chunks_) {
     CAPITAL_CHECK(capi_comm_rank(comm, &rank));
     CAPITAL_CHECK(capi_comm_size(comm, &size));
@@ -35,12 +39,19 @@ public:
     d = detail::isqrt_ceil(size / c);                                   // topology.h:77
     if (d * d * c != (size_t)size) throw std::invalid_argument("topo::square: size must be d*d*c");
     const size_t TopFaceSize = d * c, FrontFaceSize = d * d;
-    if (layout == 0) {                                                  // topology.h:80-95
-      z = rank % c; y = rank / TopFaceSize; x = (rank % TopFaceSize) / c;
-    } else if (layout == 1) {                                           // topology.h:96-103
-      y = rank % d; x = (rank % FrontFaceSize) / d; z = rank / FrontFaceSize;
-    } else {
-      throw std::invalid_argument("topo::square: layout 2 (64-rank sub-cubes, topology.h:104-123) is a multi-node layout; not offered on one node");
+    if (layout > 2) throw std::invalid_argument("topo::square: layout must be 0, 1 or 2");
+    coords(rank, x, y, z);
+    if (layout == 2) {
+      // 64-rank sub-cubes (topology.h:104-123): only meaningful when the rule yields a bijection onto the d x d x c grid
+      // (it does for cubic grids, c == d, up to 64 ranks -- on one node it then coincides with layout 1)
+      std::vector<char> seen((size_t)size, 0);
+      for (int r = 0; r < size; ++r) {
+        size_t px, py, pz;
+        coords(r, px, py, pz);
+        const size_t id = px + d * py + d * d * pz;
+        if (px >= d || py >= d || pz >= c || seen[id]) throw std::invalid_argument("topo::square: layout 2 does not tile this grid (needs a cubic grid, c == d)");
+        seen[id] = 1;
+      }
     }
     world = comm;
     depth = detail::split(comm, (int)(x + d * y), (int)z);              // same (x,y), ordered by z
@@ -52,9 +63,36 @@ public:
   square& operator=(const square&) = delete;
   ~square() { detail::release(row); detail::release(column); detail::release(slice); detail::release(depth); }
 
+  // grid position of a world rank under this layout (topology.h:80-123)
+  void coords(int r, size_t& px, size_t& py, size_t& pz) const {
+    const size_t TopFaceSize = d * c, FrontFaceSize = d * d, ur = (size_t)r;
+    if (layout == 0) {                                                  // topology.h:80-95
+      pz = ur % c; py = ur / TopFaceSize; px = (ur % TopFaceSize) / c;
+    } else if (layout == 1) {                                           // topology.h:96-103
+      py = ur % d; px = (ur % FrontFaceSize) / d; pz = ur / FrontFaceSize;
+    } else {                                                            // topology.h:104-123
+      const size_t sub = (size_t)std::min(size, 64);
+      const size_t sub_slice = (size_t)std::llround(std::ceil(std::pow((double)sub, 2. / 3.) - 1e-9));
+      const size_t sub_dim = (size_t)std::llround(std::ceil(std::pow((double)sub, 1. / 3.) - 1e-9));
+      const size_t rmod = ur % sub, rdiv = ur / sub;
+      const size_t lx = (rmod % sub_slice) / sub_dim, ly = rmod % sub_dim, lz = rmod / sub_slice;
+      const size_t per = c / sub_dim ? c / sub_dim : 1;
+      const size_t gx = TopFaceSize >= sub_slice ? (rdiv % (TopFaceSize / sub_slice)) / per : 0;
+      const size_t gy = rdiv % per;
+      const size_t gz = TopFaceSize >= sub_slice ? rdiv / (TopFaceSize / sub_slice) : 0;
+      px = gx * sub_dim + lx; py = gy * sub_dim + ly; pz = gz * sub_dim + lz;
+    }
+  }
   // world rank of grid position (x,y,z) under this layout (util::transpose's partner rule, util.hpp:237-239)
   int rank_of(size_t px, size_t py, size_t pz) const {
-    return layout == 0 ? (int)(pz + c * px + c * d * py) : (int)(py + d * px + d * d * pz);
+    if (layout == 0) return (int)(pz + c * px + c * d * py);
+    if (layout == 1) return (int)(py + d * px + d * d * pz);
+    for (int r = 0; r < size; ++r) {
+      size_t qx, qy, qz;
+      coords(r, qx, qy, qz);
+      if (qx == px && qy == py && qz == pz) return r;
+    }
+    return -1;
   }
 
   capi_comm_t world = nullptr, row = nullptr, column = nullptr, slice = nullptr, depth = nullptr;

@@ -93,6 +93,31 @@ def test_cholinv_on_grids(oracle, shim_lib, world, c, n, bc, ci, serialize, poli
         assert len(levels) == 1            # every rank walked the same recursion
 
 
+@pytest.mark.parametrize("world,c,layout", [(8, 2, 1), (8, 2, 2), (4, 1, 1)])
+def test_cholinv_rank_layouts(oracle, shim_lib, world, c, layout):
+    """rank -> (x,y,z) layouts 1 and 2 of topo::square (topology.h:96-123): the grid positions change, the factor does not"""
+    n, bc, ci = 96, -1, 1
+    with tempfile.TemporaryDirectory() as d:
+        _launch(world, {"kind": "cholinv", "n": n, "c": c, "bc": bc, "ci": ci, "serialize": False, "policy": 0, "layout": layout, "dir": d})
+        A = oracle.distribute_symmetric(n, n, 0, 0, 1, 1)
+        Rg, Ig = np.zeros((n, n), order="F"), np.zeros((n, n), order="F")
+        seen = set()
+        for r in range(world):
+            z = np.load(os.path.join(d, f"rank{r}.npz"))
+            x, y, zz, dd, cc = [int(v) for v in z["xyz"]]
+            # the reference's rule for layout 1 (and layout 2 on <= 64 ranks of a cubic grid, which coincides with it)
+            assert (x, y, zz) == ((r % (dd * dd)) // dd, r % dd, r // (dd * dd))
+            seen.add((x, y, zz))
+            if zz == 0:
+                oracle.cyclic_insert(Rg, np.asfortranarray(z["R"]), x, y, dd, dd)
+                oracle.cyclic_insert(Ig, np.asfortranarray(z["Rinv"]), x, y, dd, dd)
+        assert len(seen) == world
+        Rref, Iref, info = oracle.cholinv_factor(A, ci, 1, bc, c, dd)
+        assert info == 0
+        assert np.abs(Rg - Rref).max() <= 1e-12 * np.abs(Rref).max()
+        assert np.abs(Ig - Iref).max() <= 1e-12 * np.abs(Iref).max()
+
+
 def test_depth_replicas_agree(oracle, shim_lib):
     with tempfile.TemporaryDirectory() as d:
         _launch(8, {"kind": "cholinv", "n": 64, "c": 2, "bc": -1, "ci": 1, "serialize": False, "policy": 0, "dir": d})

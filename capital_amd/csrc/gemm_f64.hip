@@ -52,6 +52,17 @@ constexpr bool STORE_IN_SHADOW = CAPI_STORE_IN_SHADOW;
 #define CAPI_LOADS_IN_SHADOW 1
 #endif
 constexpr bool LOADS_IN_SHADOW_ON = CAPI_LOADS_IN_SHADOW;
+// A row-contiguous operand ([k][row] in HBM) is transposed while it is staged, so that LDS holds every operand [row][k] and all
+// four variants run the k-contiguous variant's inner loop (16-byte fragment reads, the pinned schedule).
+#ifndef CAPI_TRANSPOSE_STAGE
+#define CAPI_TRANSPOSE_STAGE 1
+#endif
+constexpr bool TRANSPOSE_STAGE = CAPI_TRANSPOSE_STAGE;
+// thread -> element map of a row-contiguous operand's panel when it is staged transposed: piece q of thread tid is rows
+// rc_r, rc_r + 1 at k = rc_k.  A wave instruction covers 16 rows x 8 k: eight whole 128-byte lines on the way in, and
+// (rows 18 doubles apart in LDS) bank pairs (8 rp + 2 k) mod 64 on the way out -- two-way conflicts at most.
+template <int TS> __device__ __forceinline__ int rc_r(int tid, int q) { return 16 * ((tid >> 6) * (TS / 64) + (q >> 1)) + 2 * (tid & 7); }
+__device__ __forceinline__ int rc_k(int tid, int q) { return 8 * (q & 1) + ((tid >> 3) & 7); }
 
 struct GemmArgs {
   const double* A;
@@ -103,10 +114,10 @@ __device__ __forceinline__ void panel_load(const double* __restrict__ X, int64_t
     }
   } else {  // element (r,k) at X[r + k*ld]
     const int rp = tid & (TS / 2 - 1), kb = tid / (TS / 2);
-    const int r = r0 + 2 * rp;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const int k = k0 + kb + (512 / TS) * q;
+      const int r = r0 + (TRANSPOSE_STAGE ? rc_r<TS>(tid, q) : 2 * rp);
+      const int k = k0 + (TRANSPOSE_STAGE ? rc_k(tid, q) : kb + (512 / TS) * q);
       d2_t val = {0.0, 0.0};
       if (k < kend) {
         const double* p = X + (int64_t)k * ld + r;
@@ -123,11 +134,11 @@ __device__ __forceinline__ void panel_load(const double* __restrict__ X, int64_t
 }
 
 // interior fast path: the whole panel is in range and 16-byte aligned -- four straight-line loads, no predicates.
-// `base` already points at this thread's first piece of the panel; `stride` (elements) separates its pieces.
+// `base` already points at this thread's first piece of the panel; piece q lies (q & 1) s1 + (q >> 1) s2 elements further.
 template <int TS>
-__device__ __forceinline__ void panel_load_fast(const double* __restrict__ base, int64_t stride, d2_t (&v)[TS / 32]) {
+__device__ __forceinline__ void panel_load_fast(const double* __restrict__ base, int64_t s1, int64_t s2, d2_t (&v)[TS / 32]) {
 #pragma unroll
-  for (int q = 0; q < TS / 32; ++q) v[q] = *(const d2_t*)(base + q * stride);
+  for (int q = 0; q < TS / 32; ++q) v[q] = *(const d2_t*)(base + (q & 1) * s1 + (q >> 1) * s2);
 }
 
 // zero what lies outside the triangle of op(T) (and force a unit diagonal) on a staged panel.
@@ -142,9 +153,9 @@ __device__ __forceinline__ void panel_mask(int r0, int k0, int tid, bool keep_ge
       k[0] = k0 + 2 * (tid & 7);
       k[1] = k[0] + 1;
     } else {
-      r[0] = r0 + 2 * (tid & (TS / 2 - 1));
+      r[0] = r0 + (TRANSPOSE_STAGE ? rc_r<TS>(tid, q) : 2 * (tid & (TS / 2 - 1)));
       r[1] = r[0] + 1;
-      k[0] = k[1] = k0 + tid / (TS / 2) + (512 / TS) * q;
+      k[0] = k[1] = k0 + (TRANSPOSE_STAGE ? rc_k(tid, q) : tid / (TS / 2) + (512 / TS) * q);
     }
     double e0 = v[q].x, e1 = v[q].y;
     if (keep_ge ? (k[0] < r[0]) : (k[0] > r[0])) e0 = 0.0;
@@ -165,6 +176,13 @@ __device__ __forceinline__ void panel_store(double* __restrict__ L, int tid, con
     const int kp = tid & 7, rb = tid >> 3;
 #pragma unroll
     for (int q = 0; q < TS / 32; ++q) *(d2_t*)&L[(rb + 32 * q) * SK + 2 * kp] = v[q];
+  } else if (TRANSPOSE_STAGE) {
+#pragma unroll
+    for (int q = 0; q < TS / 32; ++q) {
+      double* d = &L[rc_r<TS>(tid, q) * SK + rc_k(tid, q)];
+      d[0] = v[q].x;
+      d[SK] = v[q].y;
+    }
   } else {
     const int rp = tid & (TS / 2 - 1), kb = tid / (TS / 2);
 #pragma unroll
@@ -177,7 +195,7 @@ __device__ __forceinline__ void panel_store(double* __restrict__ L, int tid, con
 template <int TS, bool KC>
 __device__ __forceinline__ d2_t frag_read(const double* __restrict__ L, int row, int u, int g) {
   constexpr int SR = tile_cfg<TS>::SR;
-  if (KC) {
+  if (KC || TRANSPOSE_STAGE) {
     return *(const d2_t*)&L[row * SK + 8 * u + 2 * g];
   } else {
     d2_t f;
@@ -261,7 +279,8 @@ __global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel
   constexpr int BM = TS, BN = TS, SUB = tile_cfg<TS>::SUB, NQ = tile_cfg<TS>::NQ;
   // the fully pinned iteration schedule counts 16-byte fragment reads: both operands k-contiguous (measured: +1.5 % there,
   // -3 % on the variants whose row-contiguous operand is read in 8-byte pieces)
-  constexpr bool LOADS_IN_SHADOW = LOADS_IN_SHADOW_ON && AK && BKC;
+  constexpr bool LOADS_IN_SHADOW = LOADS_IN_SHADOW_ON && ((AK && BKC) || TRANSPOSE_STAGE);
+  constexpr int NW = NQ * ((AK || !TRANSPOSE_STAGE ? 1 : 2) + (BKC || !TRANSPOSE_STAGE ? 1 : 2));   // LDS stores of one staging pass
   constexpr int TILE_LDS = tile_cfg<TS>::TILE_LDS, STAGE_LDS = tile_cfg<TS>::STAGE_LDS;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int tid = threadIdx.x;
@@ -310,10 +329,16 @@ __global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel
   // per-thread source of the fast path (see panel_load for the thread -> element map)
   const bool interior = (i0 + BM <= p.M) && (j0 + BN <= p.N) && p.a_vec && p.b_vec;
   const double* fa = AK ? p.A + (int64_t)(i0 + (tid >> 3)) * p.lda + klo + 2 * (tid & 7)
-                        : p.A + (int64_t)(klo + tid / (TS / 2)) * p.lda + i0 + 2 * (tid & (TS / 2 - 1));
+                     : TRANSPOSE_STAGE ? p.A + (int64_t)(klo + rc_k(tid, 0)) * p.lda + i0 + rc_r<TS>(tid, 0)
+                                       : p.A + (int64_t)(klo + tid / (TS / 2)) * p.lda + i0 + 2 * (tid & (TS / 2 - 1));
   const double* fb = BKC ? p.B + (int64_t)(j0 + (tid >> 3)) * p.ldb + klo + 2 * (tid & 7)
-                         : p.B + (int64_t)(klo + tid / (TS / 2)) * p.ldb + j0 + 2 * (tid & (TS / 2 - 1));
-  const int64_t qsa = AK ? 32 * p.lda : (512 / TS) * p.lda, qsb = BKC ? 32 * p.ldb : (512 / TS) * p.ldb;
+                     : TRANSPOSE_STAGE ? p.B + (int64_t)(klo + rc_k(tid, 0)) * p.ldb + j0 + rc_r<TS>(tid, 0)
+                                       : p.B + (int64_t)(klo + tid / (TS / 2)) * p.ldb + j0 + 2 * (tid & (TS / 2 - 1));
+  // piece q of the fast path lies (q & 1) qsa + (q >> 1) qsa2 elements behind piece 0
+  const int64_t qsa = AK ? 32 * p.lda : TRANSPOSE_STAGE ? 8 * p.lda : (512 / TS) * p.lda;
+  const int64_t qsa2 = AK ? 64 * p.lda : TRANSPOSE_STAGE ? 16 : 2 * (512 / TS) * p.lda;
+  const int64_t qsb = BKC ? 32 * p.ldb : TRANSPOSE_STAGE ? 8 * p.ldb : (512 / TS) * p.ldb;
+  const int64_t qsb2 = BKC ? 64 * p.ldb : TRANSPOSE_STAGE ? 16 : 2 * (512 / TS) * p.ldb;
   const int64_t ksa = AK ? kstep : (int64_t)kstep * p.lda, ksb = BKC ? kstep : (int64_t)kstep * p.ldb;
 
   // triangular output: on a diagonal tile the sub-tiles lying entirely in the unwanted triangle are never computed
@@ -360,8 +385,8 @@ __global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel
       fa += ksa;
       fb += ksb;
       if (LOADS_IN_SHADOW) __builtin_amdgcn_s_setprio(1);     // one scheduling region from here to the end of the MFMAs
-      panel_load_fast<TS>(fa, qsa, ra);
-      panel_load_fast<TS>(fb, qsb, rb);       // (on a shared diagonal tile this re-reads A's panel: cache hit, never staged)
+      panel_load_fast<TS>(fa, qsa, qsa2, ra);
+      panel_load_fast<TS>(fb, qsb, qsb2, rb);       // (on a shared diagonal tile this re-reads A's panel: cache hit, never staged)
     } else if (more) {
       panel_load<TS, AK>(p.A, p.lda, i0, p.M, kn, khi, tid, p.a_vec, ra);
       if (!shareB) panel_load<TS, BKC>(p.B, p.ldb, j0, p.N, kn, khi, tid, p.b_vec, rb);
@@ -425,8 +450,8 @@ __global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel
           }
         }
 #pragma unroll
-        for (int i = 0; i < 2 * NQ; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, (2 * SUB * SUB) / (2 * NQ), 0);   // MFMA
+        for (int i = 0; i < NW; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, (2 * SUB * SUB) / NW > 0 ? (2 * SUB * SUB) / NW : 1, 0);   // MFMA
           __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                           // DS write
         }
       }

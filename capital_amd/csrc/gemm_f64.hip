@@ -7,9 +7,9 @@
 //     each wave owns a 64x64 block = 4x4 MFMA tiles of 16x16 (64 fp64 accumulators per lane);
 //   * K is consumed in 16-deep panels, double-buffered in LDS (one barrier per panel), staged
 //     global -> registers (16-byte coalesced loads) -> LDS while the MFMAs of the current panel run;
-//   * an operand panel is kept in LDS in the orientation it has in HBM (k-contiguous [row][k] with
-//     a 2-double pad, or row-contiguous [k][row] with an 8-double pad) so that staging is a pure
-//     16-byte copy and fragment reads are bank-conflict free or at worst 2-way;
+//   * every operand panel sits in LDS k-contiguous ([row][k] with a 2-double pad): a k-contiguous operand is staged
+//     by a pure 16-byte copy, a row-contiguous one is transposed on the way in (16-byte loads of two rows at one k,
+//     two 8-byte LDS stores), so all four variants read 16-byte fragments and share one pinned inner loop;
 //   * the MFMA's A operand is fed from the N-side panel and its B operand from the M-side panel, so the
 //     accumulator's lane index runs along C's column-major rows and the epilogue stores 128-byte runs;
 //   * triangular work is skipped at tile granularity: GEMMT/SYRK launch only the tiles of the wanted
@@ -19,11 +19,11 @@
 //   * workgroup ids are re-dealt so that the 64 tiles an XCD runs concurrently form a compact block
 //     of the output (8 XCDs x private 4 MiB L2).
 // Around it, in this file: dgemm_small_kernel (order <= 512: 32 x 32 tiles, K in 256-deep bursts -- the recursion's
-// latency-bound levels), gram_ts_kernel and trmm_right_ts_kernel (CholeskyQR2's tall-skinny Gram matrix and Q = A R^-1,
+// latency-bound levels), gram_ts_kernel and trmm_right_ts32_kernel (CholeskyQR2's tall-skinny Gram matrix and Q = A R^-1,
 // full-width workgroups that read the tall operand once), and launch_gemm, which picks between them with a makespan
 // model in CU-cycles.
 // Diagnostic environment switches (read once): CAPI_DEBUG_GEMM (print every choice), CAPI_FORCE_TS=64|128, CAPI_SMALL=0|1,
-// CAPI_NO_TS, CAPI_NO_SHARE, CAPI_NO_SKIP, CAPI_NO_ROTATE, CAPI_PEAK_BLOCKS_PER_CU.
+// CAPI_NO_TS, CAPI_TS_ROWS16, CAPI_NO_SHARE, CAPI_NO_SKIP, CAPI_NO_ROTATE, CAPI_NO_TAIL, CAPI_THIN_ROUNDS, CAPI_PEAK_BLOCKS_PER_CU.
 #include "capi_internal.h"
 #include <type_traits>
 

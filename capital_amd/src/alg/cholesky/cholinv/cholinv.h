@@ -246,17 +246,21 @@ private:
       }
       CAPITAL_CHECK(capi_dlacpy(h, 0, split1, split2, W.p, W.ld, A12.p, ld));            // R12 into R (cholinv.hpp:122)
       CRITTER_STOP(CI::trsm);
-      if (top && !std::is_same<typename SP::structure, rect>::value) {
-        // R11, R12 and Rinv11 are final: pack them beside the trailing update and the right half (second stream)
-        CAPITAL_CHECK(capi_event_record(h, EV_TOP_R12));
+      // R11, R12 and Rinv11 are final after step 2: they are packed on the second stream.  Without lookahead the packing
+      // starts at once, beside the trailing update; with it, it waits for the bulk of the top-level update and then runs
+      // beside the trailing block's latency-bound chain, where the GPU is otherwise idle (beside a tile kernel the packing
+      // kernels' short workgroups keep whole CUs from the 512-thread-per-CU tile workgroups: the update lost ~10 %)
+      auto early_pack = [&](int after_ev) {
         CAPITAL_CHECK(capi_stream_select(h, 1));
-        CAPITAL_CHECK(capi_event_wait(h, EV_TOP_R12));
+        CAPITAL_CHECK(capi_event_wait(h, after_ev));
         pack_block(args, CAPI_UPPERTRI, R, (double*)args.R.data(), ld, (U)0, split1, (U)0, split1);
         pack_block(args, CAPI_RECT, R, (double*)args.R.data(), ld, split1, ld, (U)0, split1);
         pack_block(args, CAPI_UPPERTRI, Ri, (double*)args.Rinv.data(), ld, (U)0, split1, (U)0, split1);
         CAPITAL_CHECK(capi_event_record(h, EV_EARLY_PACK));
         CAPITAL_CHECK(capi_stream_select(h, 0));
-      }
+      };
+      const bool pack_now = top && !std::is_same<typename SP::structure, rect>::value;
+      bool packed_early = false;
 
       CRITTER_START(CI::tmu);                                                           // 3
       // Lookahead: the trailing block's recursion starts with a long chain of latency-bound kernels on its leading
@@ -279,6 +283,7 @@ private:
         CAPITAL_CHECK(capi_stream_select(h, 0));
         child_wait = EV_LA_REST + depth;
         ++args.la_depth;                  // W stays allocated until the trailing block's recursion has joined
+        if (pack_now && !getenv("CAPITAL_PACK_AT_ONCE")) { early_pack(EV_LA_REST + depth); packed_early = true; }
       } else if (single) {
         CAPITAL_CHECK(capi_dgemmt(h, CAPI_UPPER, CAPI_TRANS, CAPI_NOTRANS, split2, split1, -1.0, W.p, W.ld, W.p, W.ld, 1.0, A22.p, ld));
       } else {
@@ -286,6 +291,10 @@ private:
         capital::dev_copy(Wx.p, W.p, W.count());
         util::transpose_raw(Wx.p, Wx.count(), ws.take(Wx.count()), t);
         matmult::summa::syrk(t, CAPI_UPPER, CAPI_TRANS, -1.0, W, Wx, 1.0, A22, ws);
+      }
+      if (pack_now && !packed_early) {
+        CAPITAL_CHECK(capi_event_record(h, EV_TOP_R12));
+        early_pack(EV_TOP_R12);
       }
       if (child_wait < 0) ws.top = mark;
       CRITTER_STOP(CI::tmu);

@@ -579,6 +579,39 @@ __global__ void splitk_reduce_kernel(const double* __restrict__ slab, int64_t sl
   }
 }
 
+// the same for many slices (the tall-skinny Gram matrix: one slice per CU): 64 rows x 4 slice-lanes per workgroup, each
+// thread sums every 4th slice with 8 loads in flight, the four partial sums are combined through LDS in a fixed order
+__global__ __launch_bounds__(256) void splitk_reduce_wide_kernel(const double* __restrict__ slab, int64_t slab_ld, int64_t slab_stride,
+                                                                 int splitk, double* __restrict__ C, int64_t ldc, int M, int N,
+                                                                 double alpha, double beta, int out_uplo) {
+  __shared__ double part[4][64];
+  const int il = threadIdx.x & 63, zl = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + il, j = blockIdx.y;
+  const bool live = i < M && !(out_uplo == CAPI_UPPER && i > j) && !(out_uplo == CAPI_LOWER && i < j);
+  double s = 0.0;
+  if (live) {
+    const double* src = slab + i + (int64_t)j * slab_ld;
+    int z = zl;
+    for (; z + 28 < splitk; z += 32) {
+      double v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = src[(int64_t)(z + 4 * q) * slab_stride];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s += v[q];
+    }
+    for (; z < splitk; z += 4) s += src[(int64_t)z * slab_stride];
+  }
+  part[zl][il] = s;
+  __syncthreads();
+  if (zl == 0 && live) {
+    const double t = ((part[0][il] + part[1][il]) + part[2][il]) + part[3][il];
+    double* c = C + i + (int64_t)j * ldc;
+    double r = alpha * t;
+    if (beta != 0.0) r += beta * (*c);
+    *c = r;
+  }
+}
+
 // scale-only path for alpha == 0 or K == 0:  C(part) <- beta*C
 __global__ void scale_kernel(double* __restrict__ C, int64_t ldc, int M, int N, double beta, int out_uplo) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1304,7 +1337,11 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
       }
       hipLaunchKernelGGL(gram_ts_kernel, dim3((unsigned)S), dim3(TSK_THREADS), lds_bytes, s, p);
       CAPI_HIP_CHECK(h, hipGetLastError());
-      if (S > 1) {
+      if (S >= 16 && p.N <= 65535) {
+        hipLaunchKernelGGL(splitk_reduce_wide_kernel, dim3((unsigned)cdiv(p.M, 64), (unsigned)p.N), dim3(256), 0, s, p.slab, p.slab_ld,
+                           p.slab_stride, p.splitk, p.C, p.ldc, p.M, p.N, p.alpha, p.beta, p.out_uplo);
+        CAPI_HIP_CHECK(h, hipGetLastError());
+      } else if (S > 1) {
         dim3 grid((unsigned)cdiv(p.M, 256), (unsigned)(p.N < 65535 ? p.N : 65535));
         hipLaunchKernelGGL(splitk_reduce_kernel, grid, dim3(256), 0, s, p.slab, p.slab_ld, p.slab_stride, p.splitk, p.C, p.ldc,
                            p.M, p.N, p.alpha, p.beta, p.out_uplo);

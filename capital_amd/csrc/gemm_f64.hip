@@ -812,6 +812,17 @@ gemm_kernel_t pick_small(bool ak, bool bkc) {
 // 8.6 GB, Q = A R^-1 with 64-tiles: 2.5 passes) and that, not the matrix pipe, sets the time.  Here one workgroup of 8
 // waves covers the FULL width, so every element of the tall operand travels global -> LDS exactly once.
 constexpr int TSK_THREADS = 512, TSK_W = 256;    // up to 16 column strips of 16
+// the tall operands are read once and written once: non-temporal accesses (CAPI_TS_NT=0 compiles the plain ones, A/B)
+#ifndef CAPI_TS_NT
+#define CAPI_TS_NT 1
+#endif
+#if CAPI_TS_NT
+#define TS_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#define TS_LOAD(ptr) __builtin_nontemporal_load(ptr)
+#else
+#define TS_STORE(ptr, val) (*(ptr) = (val))
+#define TS_LOAD(ptr) (*(ptr))
+#endif
 
 // Gram matrix, upper triangle:  slab[z] (or C) = sum over this workgroup's k-range of A[k][i] A[k][j], A k-contiguous.
 // The 16 x 16 grid of output tiles has 136 upper tiles; wave w owns tile-rows w and 15-w (17 tiles): balanced, and per
@@ -882,7 +893,7 @@ __device__ __forceinline__ void gram_ts_body(const GemmArgs& p, double* __restri
     if (STEADY) {
       const double* src = p.A + (int64_t)c0 * p.lda + pidx(it + 2) * BK + 2 * kp;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) nw[q] = *(const d2_t*)(src + (int64_t)(64 * q) * p.lda);
+      for (int q = 0; q < 4; ++q) nw[q] = TS_LOAD((const d2_t*)(src + (int64_t)(64 * q) * p.lda));
     } else if (it + 2 < np) load(pidx(it + 2), nw);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -1169,7 +1180,7 @@ __device__ __forceinline__ void trmm_ts32_body(const GemmArgs& p, double* __rest
     if (STEADY) {
       const double* src = p.A + 32 * (tile + dt) + lr + (int64_t)lc * p.lda;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) st[q] = *(const d2_t*)(src + q * 32 * p.lda);
+      for (int q = 0; q < 8; ++q) st[q] = TS_LOAD((const d2_t*)(src + q * 32 * p.lda));
     } else if (tile + dt < ntile) load(tile + dt, st);
     d4_t ca0 = {0.0, 0.0, 0.0, 0.0}, ca1 = ca0, cb0 = ca0, cb1 = ca0;
     const double* la = L + g * 16 + r16;                    // A[row r16 (+16)][k = 4 s + g]
@@ -1200,8 +1211,8 @@ __device__ __forceinline__ void trmm_ts32_body(const GemmArgs& p, double* __rest
     if (STEADY) {
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
-        c0_[reg * s4] = p.alpha * ca0[reg]; c0_[reg * s4 + 16] = p.alpha * ca1[reg];
-        c1_[reg * s4] = p.alpha * cb0[reg]; c1_[reg * s4 + 16] = p.alpha * cb1[reg];
+        TS_STORE(&c0_[reg * s4], p.alpha * ca0[reg]); TS_STORE(&c0_[reg * s4 + 16], p.alpha * ca1[reg]);
+        TS_STORE(&c1_[reg * s4], p.alpha * cb0[reg]); TS_STORE(&c1_[reg * s4 + 16], p.alpha * cb1[reg]);
       }
     } else {
       const bool ok0 = i < p.M, ok1 = i + 16 < p.M;

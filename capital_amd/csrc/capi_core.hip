@@ -150,6 +150,7 @@ int capi_stream_select(capi_handle_t h, int which) {
         uint32_t mask[16] = {0};
         for (int b = 0; b < bulk && b < 512; ++b) mask[b >> 5] |= 1u << (b & 31);
         CAPI_HIP_CHECK(h, hipExtStreamCreateWithCUMask(&h->streams[which], (uint32_t)((h->num_cu + 31) / 32), mask));
+        h->cu_of[which] = bulk;
       } else {
         int least = 0, greatest = 0;
         CAPI_HIP_CHECK(h, hipDeviceGetStreamPriorityRange(&least, &greatest));

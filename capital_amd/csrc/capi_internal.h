@@ -15,6 +15,7 @@ struct capi_handle_s {
   static constexpr int NSTREAMS = 4;
   hipStream_t streams[NSTREAMS] = {nullptr, nullptr, nullptr, nullptr};
   int cur = 0;                    // index of the selected stream
+  int cu_of[NSTREAMS] = {0, 0, 0, 0};   // CUs a stream may use when it carries a CU mask (0 = all): launch heuristics count rounds with it
   hipEvent_t* events = nullptr;   // 1024 lazily created slots
   // private workspace (in-place trmm staging, split-K slabs, potrf panels); grows on demand.  One per stream index:
   // reuse is stream-ordered, so work on different streams must not share a block

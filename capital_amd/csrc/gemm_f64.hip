@@ -1376,7 +1376,7 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
     const double nt = (double)count_tiles(p, ts);
     const double cyc = ts == 128 ? 4096.0 : 1024.0;
     const double eff = ts == 128 ? 0.89 : 0.80;          // measured pipe utilisation of the two kernels (fast path)
-    const int ncu = h->num_cu;
+    const int ncu = h->cu_of[h->cur] ? h->cu_of[h->cur] : h->num_cu;
     for (int sk = 1; sk <= 512; ++sk) {
       if (sk > 1 && (!ws_for_slab || p.K / sk < 256)) break;
       double busiest;                                     // cycles of work queued on the busiest CU
@@ -1481,7 +1481,7 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
   // tail is re-cut into 64-tiles (4x the workgroups, a quarter of the length) and launched right behind the full rounds.
   int tail128 = 0;
   if (p.ts == 128 && p.splitk == 1 && !tri && !getenv("CAPI_NO_TAIL")) {
-    const int per_round = 2 * h->num_cu;
+    const int per_round = 2 * (h->cu_of[h->cur] ? h->cu_of[h->cur] : h->num_cu);
     const int rem = p.ntiles % per_round;
     if (p.ntiles >= 2 * per_round && rem > 0 && rem <= (3 * per_round) / 4) tail128 = rem;
   }

@@ -229,9 +229,12 @@ def test_randomized_shapes_against_numpy(hip):
     128-tile kernels, split-K and the ragged edges of each), odd leading dimensions, all flag combinations; numpy fp64 as
     the reference, 1e-13 * k relative to the largest entry.  Rows of C beyond m (ld padding) must stay untouched."""
     from capital_amd import capi
-    rng = np.random.default_rng(20261004)
+    # CAPITAL_FUZZ_SEED / CAPITAL_FUZZ_CASES widen the sweep for one-off runs (e.g. with CAPI_FORCE_TS=128 CAPI_SMALL=0 in the
+    # environment, which pins the kernel choice for the whole process)
+    import os
+    rng = np.random.default_rng(int(os.environ.get("CAPITAL_FUZZ_SEED", "20261004")))
     dims = lambda hi=700: int(rng.choice([1, 2, 15, 16, 17, 31, 33, 63, 64, 65, 127, 129, 255, 257, 511, 513, int(rng.integers(1, hi))]))
-    for case in range(120):
+    for case in range(int(os.environ.get("CAPITAL_FUZZ_CASES", "120"))):
         kind = case % 4
         pad = int(rng.integers(0, 4))
         alpha, beta = float(rng.uniform(-2, 2)), float(rng.choice([0.0, 1.0, rng.uniform(-2, 2)]))

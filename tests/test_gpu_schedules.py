@@ -64,6 +64,28 @@ def test_cholinv_lookahead_matches_oracle(drv, oracle, monkeypatch, n, bc, ci, s
     p.close()
 
 
+def test_cholinv_lookahead_random_orders(drv, oracle, monkeypatch):
+    """random orders / base-case depths / split shifts with the lookahead forced on at every level (8 cases by default;
+    CAPITAL_FUZZ_CASES widens the sweep for one-off runs)"""
+    import os
+    rng = np.random.default_rng(int(os.environ.get("CAPITAL_FUZZ_SEED", "7")))
+    monkeypatch.setenv("CAPITAL_LOOKAHEAD_MIN", "32")
+    for _ in range(int(os.environ.get("CAPITAL_FUZZ_CASES", "8"))):
+        n = int(rng.integers(200, 1800))
+        bc, ci, split = -int(rng.integers(1, 5)), int(rng.integers(2)), int(rng.choice([1, 1, 1, 2]))
+        p = drv.Cholinv(n, c=1, complete_inv=ci, split=split, bc_mult=bc, serialize=bool(rng.integers(2)), bc_policy=2)
+        p.generate()
+        A = p.A()
+        p.factor()
+        R, Ri = p.R(), p.Rinv()
+        Rref, Riref, info = oracle.cholinv_factor(A, ci, split, bc, 1, 1)
+        assert info == 0
+        assert np.abs(R - Rref).max() <= 1e-12 * np.abs(Rref).max(), (n, bc, ci, split)
+        assert np.abs(Ri - Riref).max() <= 1e-12 * np.abs(Riref).max(), (n, bc, ci, split)
+        assert np.count_nonzero(Ri) == np.count_nonzero(Riref)
+        p.close()
+
+
 def test_cholinv_repeat_is_deterministic(drv, oracle):
     p = drv.Cholinv(768, bc_mult=-2, serialize=False)
     p.generate()

@@ -19,23 +19,30 @@ __device__ __host__ inline int64_t st_offset(int st, int64_t x, int64_t y, int64
   return x * dimY + y - (x * (x + 1) / 2);
 }
 
+// each thread moves up to four elements of a column, 256 apart, with all its loads in flight before the first store
 __global__ void serialize_kernel(int shape, int ss, int ds, const double* __restrict__ src, int64_t sdimY, double* __restrict__ dst,
                                  int64_t ddimY, int64_t ssx, int64_t ssy, int64_t dsx, int64_t dsy, int64_t rangeX,
                                  int64_t rangeY) {
-  const int64_t y = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (int64_t i = blockIdx.y; i < rangeX; i += gridDim.y) {
+  const int64_t y = (int64_t)blockIdx.x * 1024 + threadIdx.x;
   const bool lower = shape == CAPI_LOWERTRI, upper = shape == CAPI_UPPERTRI;
-  int64_t so, d_o, cnt;
-  if (lower) {
-    so = st_offset(ss, ssx + i, ssy + i, sdimY);
-    d_o = st_offset(ds, dsx + i, dsy + i, ddimY);
-    cnt = rangeY - i;
-  } else {
-    so = st_offset(ss, ssx + i, ssy, sdimY);
-    d_o = st_offset(ds, dsx + i, dsy, ddimY);
-    cnt = upper ? i + 1 : rangeY;
-  }
-  if (y < cnt) dst[d_o + y] = src[so + y];
+  for (int64_t i = blockIdx.y; i < rangeX; i += gridDim.y) {
+    int64_t so, d_o, cnt;
+    if (lower) {
+      so = st_offset(ss, ssx + i, ssy + i, sdimY);
+      d_o = st_offset(ds, dsx + i, dsy + i, ddimY);
+      cnt = rangeY - i;
+    } else {
+      so = st_offset(ss, ssx + i, ssy, sdimY);
+      d_o = st_offset(ds, dsx + i, dsy, ddimY);
+      cnt = upper ? i + 1 : rangeY;
+    }
+    if (y >= cnt) continue;                               // (whole workgroups above a triangle's diagonal leave here)
+    double v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = src[so + (y + 256 * q < cnt ? y + 256 * q : y)];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (y + 256 * q < cnt) dst[d_o + y + 256 * q] = v[q];
   }
 }
 
@@ -215,7 +222,7 @@ int capi_serialize_shape(capi_handle_t h, int shape, int ss, int ds, const doubl
   const int64_t rangeX = sex - ssx, rangeY = sey - ssy;
   if (rangeX <= 0 || rangeY <= 0) return CAPI_OK;
   CAPI_REQUIRE(h, src && dst, "null matrix");
-  hipLaunchKernelGGL(serialize_kernel, grid2(rangeY, rangeX), dim3(256), 0, h->stream, shape, ss, ds, src, sdimY, dst, ddimY, ssx, ssy,
+  hipLaunchKernelGGL(serialize_kernel, dim3((unsigned)cdiv(rangeY, 1024), (unsigned)(rangeX < 65535 ? rangeX : 65535)), dim3(256), 0, h->stream, shape, ss, ds, src, sdimY, dst, ddimY, ssx, ssy,
                      dsx, dsy, rangeX, rangeY);
   CAPI_HIP_CHECK(h, hipGetLastError());
   return CAPI_OK;

@@ -57,6 +57,7 @@ public:
     // top-level overlap state: the input's right part is copied, and the finished left part packed, on the second stream
     const double* input = nullptr;
     DimensionType early_split = 0;
+    DimensionType input_lead = 0;       // > 0: only this leading block of the input's left half was copied on the compute stream
     // trailing updates currently running beside the recursion on the bulk streams (single-GPU lookahead)
     int la_depth = 0;
   };
@@ -106,12 +107,23 @@ public:
     args.input = A.data();
     args.early_split = 0;
     const bool will_split = !(((localDimension * (U)CommInfo.d) <= args.bcDimension) || (h1 < args.split));   // cholinv.hpp:93
+    args.input_lead = 0;
     if (will_split && h1 > 0 && h1 < ld) {
       capi_handle_t hh = capital::handle();
-      CAPITAL_CHECK(capi_dlacpy(hh, 1, h1, h1, A.data(), ld, R, ld));
+      // the left spine starts on the leading blocks: when the recursion halves cleanly down to `lead`, only that block is
+      // copied ahead of it; the rest of the left half follows on the second stream and is awaited by the node of order 2 lead
+      U lead = h1;
+      if (args.split == 1 && CommInfo.d == 1 && CommInfo.c == 1) while (lead >= 8192 && lead % 2 == 0 && (lead >> 1) * (U)CommInfo.d > args.bcDimension) lead >>= 1;
+      CAPITAL_CHECK(capi_dlacpy(hh, 1, lead, lead, A.data(), ld, R, ld));
       CAPITAL_CHECK(capi_event_record(hh, EV_INPUT_HEAD));
       CAPITAL_CHECK(capi_stream_select(hh, 1));
       CAPITAL_CHECK(capi_event_wait(hh, EV_INPUT_HEAD));       // (also orders this call after the previous call's packing)
+      if (lead < h1) {
+        CAPITAL_CHECK(capi_dlacpy(hh, 0, lead, h1 - lead, A.data() + (int64_t)lead * ld, ld, R + (int64_t)lead * ld, ld));
+        CAPITAL_CHECK(capi_dlacpy(hh, 1, h1 - lead, h1 - lead, A.data() + lead + (int64_t)lead * ld, ld, R + lead + (int64_t)lead * ld, ld));
+        CAPITAL_CHECK(capi_event_record(hh, EV_INPUT_MID));
+        args.input_lead = lead;
+      }
       CAPITAL_CHECK(capi_dlacpy(hh, 0, h1, ld - h1, A.data() + (int64_t)h1 * ld, ld, R + (int64_t)h1 * ld, ld));
       CAPITAL_CHECK(capi_dlacpy(hh, 1, ld - h1, ld - h1, A.data() + h1 + (int64_t)h1 * ld, ld, R + h1 + (int64_t)h1 * ld, ld));
       CAPITAL_CHECK(capi_event_record(hh, EV_INPUT_REST));
@@ -162,7 +174,7 @@ public:
 
 private:
   // event slots of the top-level overlap (matmult::summa's pipe uses slots below 1000)
-  static constexpr int EV_INPUT_HEAD = 1020, EV_INPUT_REST = 1021, EV_TOP_R12 = 1022, EV_EARLY_PACK = 1023;
+  static constexpr int EV_INPUT_HEAD = 1020, EV_INPUT_REST = 1021, EV_TOP_R12 = 1022, EV_EARLY_PACK = 1023, EV_INPUT_MID = 1019;
   // lookahead (single GPU): slot + depth; the bulk streams are stream indices LA_STREAM0 + depth
   static constexpr int EV_LA_LEAD = 1010, EV_LA_REST = 1014, LA_STREAM0 = 2, LA_MAX_DEPTH = 2;
   // smallest trailing block whose update is split (CAPITAL_LOOKAHEAD_MIN, default 2048; CAPITAL_NO_LOOKAHEAD turns it off);
@@ -215,6 +227,7 @@ private:
     invoke(args, t, R, Ri, ld, start, split1, globalDim >> 1);                          // 1
     // everything of this block beyond its leading part was updated by the parent on a bulk stream: join it here
     if (wait_ev >= 0) CAPITAL_CHECK(capi_event_wait(h, wait_ev));
+    if (start == 0 && args.input_lead > 0 && split1 == args.input_lead) CAPITAL_CHECK(capi_event_wait(h, EV_INPUT_MID));   // rest of the input's left half
 
     const bool top = (localDim == args.localDimension) && args.early_split == split1;
     if (top) CAPITAL_CHECK(capi_event_wait(h, EV_INPUT_REST));                          // the input's right part has landed

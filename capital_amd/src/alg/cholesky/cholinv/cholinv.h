@@ -233,6 +233,7 @@ private:
     if (top) CAPITAL_CHECK(capi_event_wait(h, EV_INPUT_REST));                          // the input's right part has landed
     CRITTER_START(CI::trsm);                                                            // 2
     int child_wait = -1;
+    bool copy_deferred = false;
     const int64_t mark = ws.top;
     {
       view W{ws.take((int64_t)split1 * split2), split1, split1, split2};
@@ -257,7 +258,15 @@ private:
         }
         matmult::summa::trmm(t, CAPI_LEFT, CAPI_UPPER, CAPI_TRANS, CAPI_NONUNIT, 1.0, Tx, A12, W, ws);
       }
-      CAPITAL_CHECK(capi_dlacpy(h, 0, split1, split2, W.p, W.ld, A12.p, ld));            // R12 into R (cholinv.hpp:122)
+      const U lead = split2 >> args.split;
+      const bool a22_splits = !(((split2 * (U)t.d) <= args.bcDimension) || (lead < args.split));
+      const bool la = single && a22_splits && lead > 0 && lookahead_min() >= 0 && (int64_t)split2 >= lookahead_min() && args.la_depth < LA_MAX_DEPTH;
+      const bool pack_now = top && !std::is_same<typename SP::structure, rect>::value;
+      // R12 into R (cholinv.hpp:122).  At the top level with lookahead and packed factors nothing reads it there before the
+      // early packing: the copy then goes with the packing, behind the bulk of the update (W stays allocated until the join)
+      const bool copy_later = la && pack_now && !getenv("CAPITAL_PACK_AT_ONCE");
+      if (!copy_later) CAPITAL_CHECK(capi_dlacpy(h, 0, split1, split2, W.p, W.ld, A12.p, ld));
+      copy_deferred = copy_later;
       CRITTER_STOP(CI::trsm);
       // R11, R12 and Rinv11 are final after step 2: they are packed on the second stream.  Without lookahead the packing
       // starts at once, beside the trailing update; with it, it waits for the bulk of the top-level update and then runs
@@ -266,22 +275,20 @@ private:
       auto early_pack = [&](int after_ev) {
         CAPITAL_CHECK(capi_stream_select(h, 1));
         CAPITAL_CHECK(capi_event_wait(h, after_ev));
+        if (copy_later) CAPITAL_CHECK(capi_dlacpy(h, 0, split1, split2, W.p, W.ld, A12.p, ld));
         pack_block(args, CAPI_UPPERTRI, R, (double*)args.R.data(), ld, (U)0, split1, (U)0, split1);
         pack_block(args, CAPI_RECT, R, (double*)args.R.data(), ld, split1, ld, (U)0, split1);
         pack_block(args, CAPI_UPPERTRI, Ri, (double*)args.Rinv.data(), ld, (U)0, split1, (U)0, split1);
         CAPITAL_CHECK(capi_event_record(h, EV_EARLY_PACK));
         CAPITAL_CHECK(capi_stream_select(h, 0));
       };
-      const bool pack_now = top && !std::is_same<typename SP::structure, rect>::value;
       bool packed_early = false;
 
       CRITTER_START(CI::tmu);                                                           // 3
       // Lookahead: the trailing block's recursion starts with a long chain of latency-bound kernels on its leading
       // part, which needs only that part updated.  Update it first; the rest of the update runs on a low-priority
       // bulk stream beside that chain and is joined before the trailing block's own R12 product.
-      const U lead = split2 >> args.split;
-      const bool a22_splits = !(((split2 * (U)t.d) <= args.bcDimension) || (lead < args.split));
-      if (single && a22_splits && lead > 0 && lookahead_min() >= 0 && (int64_t)split2 >= lookahead_min() && args.la_depth < LA_MAX_DEPTH) {
+      if (la) {
         const int depth = args.la_depth;
         const U rest = split2 - lead;
         double* Wr = W.p + (int64_t)lead * W.ld;
@@ -318,6 +325,7 @@ private:
 
     CRITTER_START(CI::tmu);                                                             // 5
     if (!(!args.complete_inv && (globalDim == args.trueGlobalDimension))) {
+      if (copy_deferred) CAPITAL_CHECK(capi_event_wait(h, EV_EARLY_PACK));              // R12 reached R on the second stream
       const int64_t mark = ws.top;
       view W2{ws.take((int64_t)split1 * split2), split1, split1, split2};
       matmult::summa::trmm(t, CAPI_LEFT, CAPI_UPPER, CAPI_NOTRANS, CAPI_NONUNIT, 1.0, R11i, A12, W2, ws);

@@ -3,7 +3,7 @@
 //
 // Same call surface: cacqr<SerializePolicy,IntermediatesPolicy>::factor(A, args, rectTopo), construct_Q / construct_R,
 // info<T,U,CholeskyInversionType>(num_iter, ci_args).  c == 1 is the 1-D variant (BASELINE configs 3 and 5, the hot path);
-// c == d is the 3-D variant on a cubic grid (sweep_3d below).  1-D, per sweep (cacqr.hpp:7-29):
+// c == d is the 3-D variant on a cubic grid (sweep_3d below); 1 < c < d with c | d the tunable grid (d/c cubes, sweep_tune).  1-D, per sweep (cacqr.hpp:7-29):
 //     K7  G = Q^T Q            capi_dsyrk, split-K over the tall dimension, upper triangle only
 //     C8  G = sum over ranks   capi_allreduce_sum over `world` (packed n(n+1)/2 doubles with Serialize)
 //     K8+K9  R = chol(G), R^-1 capi_dpotrf_trtri, replicated on every GPU
@@ -55,10 +55,12 @@ public:
     args.R._register_(gN, gN, CommInfo.c, CommInfo.c);
     if (CommInfo.c == 1) {
       invoke_1d(A, args, CommInfo);
-    } else if (CommInfo.c == CommInfo.d) {
+    } else if (CommInfo.d % CommInfo.c == 0) {
+      // c == d: one cube (sweep_3d); c < d: d/c cubes side by side (sweep_tune, cacqr.hpp:124-170) -- the same sweep per cube
+      // plus one all-reduce of the Gram block across the cubes
       invoke_3d(A, args, CommInfo);
     } else {
-      throw std::logic_error("qr::cacqr: the tunable c x d x c sweep (cacqr.hpp:124-170, 1 < c < d) needs c*c*d > 8 GPUs and is not built; use c == 1 or c == d");
+      throw std::logic_error("qr::cacqr: the c x d x c grid needs c to divide d");
     }
     if (!IP::keep_work) { args.G._destroy_(); args.Ginv._destroy_(); args.R1._destroy_(); args.Gpacked._destroy_(); }
   }
@@ -128,7 +130,7 @@ protected:
   // every rank ends with the element-cyclic (x,y) block of G = A^T A, replicated over z -- the input format of cholinv.
   template <typename Sq, typename ArgType>
   static void sweep_3d(const double* src, double* dst, int64_t m_loc, int64_t n_loc, ArgType& args, Sq& sq, matmult::arena& ws,
-                       matrix<double, int64_t, rect>& G) {
+                       matrix<double, int64_t, rect>& G, capi_comm_t across_cubes = nullptr) {
     using CI = typename std::remove_reference<ArgType>::type::cholesky_inverse_type;
     capi_handle_t h = capital::handle();
     const int64_t mark = ws.top;
@@ -140,6 +142,9 @@ protected:
     double* red = ws.take(n_loc * n_loc);
     CAPITAL_CHECK(capi_reduce_sum(sq.column, part, red, n_loc * n_loc, (int)sq.z));                                   // C9 Reduce(column)
     double* gsrc = (sq.y == sq.z) ? red : part;    // the depth root (z == y) holds the reduced block; others receive into `part`
+    // tunable grid (cacqr.hpp:147): the cubes' blocks are summed over column_alt (every rank takes part; only the depth
+    // roots' sums are used)
+    if (across_cubes) CAPITAL_CHECK(capi_allreduce_sum(across_cubes, gsrc, n_loc * n_loc));
     CAPITAL_CHECK(capi_bcast(sq.depth, gsrc, n_loc * n_loc, (int)sq.y));                                              // C9 Bcast(depth)
     capital::dev_copy(G.data(), gsrc, n_loc * n_loc);
     CRITTER_STOP(CQR::gram);
@@ -180,11 +185,12 @@ protected:
     matrix<double, int64_t, rect> G(n, n, CommInfo.c, CommInfo.c);
     matmult::arena& ws = matmult::summa::scratch_arena();
     ws.reserve(8 * m_loc * n_loc + 8 * n_loc * n_loc + 1024);
-    sweep_3d(A.data(), args.Q.data(), m_loc, n_loc, args, sq, ws, G);
+    capi_comm_t across = CommInfo.c < CommInfo.d ? CommInfo.column_alt : nullptr;
+    sweep_3d(A.data(), args.Q.data(), m_loc, n_loc, args, sq, ws, G, across);
     matrix<double, int64_t, rect> Rfinal = CI::construct_R(args.cholesky_inverse_args, sq);
     if (args.num_iter > 1) {
       matrix<double, int64_t, rect> R1 = Rfinal;                                                                     // save_R_3d
-      sweep_3d(args.Q.data(), args.Q.scratch(), m_loc, n_loc, args, sq, ws, G);
+      sweep_3d(args.Q.data(), args.Q.scratch(), m_loc, n_loc, args, sq, ws, G, across);
       args.Q.swap();
       matrix<double, int64_t, rect> R2 = CI::construct_R(args.cholesky_inverse_args, sq);
       // R = R2 * R1 on the grid (cacqr.hpp:208-211): right multiply by the triangular R1

@@ -178,3 +178,30 @@ def test_cacqr_3d_cubic_grid(oracle, shim_lib, m, n, variant, serialize, bc, ci)
         assert np.abs(Rg - Rref).max() <= 1e-12 * np.abs(Rref).max()
         assert np.abs(Qg - Qref).max() <= 1e-12 * (1 if variant == 2 else 100)
         assert oracle.qr_orthogonality(Qg) <= (1e-15 if variant == 2 else 1e-12)
+
+
+@pytest.mark.parametrize("m,n,variant,ci", [(1024, 32, 2, 1), (1000, 48, 2, 0)])
+def test_cacqr_tunable_grid(oracle, shim_lib, m, n, variant, ci):
+    """c = 2, d = 4 on 16 ranks: the tunable c x d x c grid (cacqr.hpp:124-170) -- two 2x2x2 cubes side by side, each running
+    the 3-D sweep on its rows, the Gram blocks summed across the cubes (column_alt).  Same uniqueness argument as above."""
+    world, c, d = 16, 2, 4
+    with tempfile.TemporaryDirectory() as dd:
+        _launch(world, {"kind": "cacqr", "m": m, "n": n, "c": c, "variant": variant, "serialize": False, "ci": ci, "bc": -1, "dir": dd}, timeout=900)
+        Ag, Qg, Rg = np.zeros((m, n), order="F"), np.zeros((m, n), order="F"), np.zeros((n, n), order="F")
+        Rcubes = {}
+        for r in range(world):
+            z = np.load(os.path.join(dd, f"rank{r}.npz"))
+            x, y, zz = (r % (c * c)) // c, r // (c * c), r % c            # topology.h:46-50
+            np.testing.assert_array_equal(z["A"], oracle.distribute_random(n, m, x, y, c, d, key=r // c))
+            if zz == 0:
+                oracle.cyclic_insert(Ag, np.asfortranarray(z["A"]), x, y, c, d)
+                oracle.cyclic_insert(Qg, np.asfortranarray(z["Q"]), x, y, c, d)
+                Rc = Rcubes.setdefault(y // c, np.zeros((n, n), order="F"))
+                oracle.cyclic_insert(Rc, np.asfortranarray(z["R"]), x, y % c, c, c)
+        Rg = Rcubes[0]
+        np.testing.assert_allclose(Rcubes[1], Rg, rtol=0, atol=1e-13 * np.abs(Rg).max())      # every cube holds the same R
+        Qref, Rref, info = oracle.cacqr_factor_1d(Ag, 1, variant)
+        assert info == 0
+        assert np.abs(Rg - Rref).max() <= 1e-12 * np.abs(Rref).max()
+        assert np.abs(Qg - Qref).max() <= 1e-12
+        assert oracle.qr_orthogonality(Qg) <= 1e-15

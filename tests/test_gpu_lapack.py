@@ -6,7 +6,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-SIZES = [1, 2, 17, 64, 65, 128, 200, 513, 1000, 2048]
+SIZES = [1, 2, 17, 64, 65, 128, 200, 513, 1000, 1280, 1600, 2048, 3000]   # 1280 / 1600: aggregated base cases of the 2- and 4-GPU bench grids
 
 
 def _spd(oracle, n):

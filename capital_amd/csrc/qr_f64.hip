@@ -3,13 +3,15 @@
 // caller -- CholeskyQR2 is its QR -- so this is the numerically robust fallback of SURVEY.md 8f-2, not a hot path).
 //
 // Blocked right-looking with compact-WY block reflectors of width 32:
-//   panel      dgeqr2 column by column, five small launches per column: sum of squares (fixed partial slots, reduced in
-//              a fixed order -> bit-reproducible), reflector (dlarfg: beta = -sign(alpha) ||x||, tau = (beta-alpha)/beta,
-//              v = x / (alpha - beta)), v^T A over the rest of the panel, its reduction, and the rank-1 update;
+//   panel      dgeqr2 column by column, two launches per column: a one-workgroup kernel turns the column's partial sums
+//              (x^T x and x^T A_c, fixed slots added in a fixed order -> bit-reproducible) into the reflector (dlarfg:
+//              beta = -sign(alpha) ||x||, tau = (beta-alpha)/beta, v = x / (alpha - beta)) and w = tau v^T A; ONE pass over the
+//              rest of the panel then scales x, applies the rank-1 update and accumulates the next column's partial sums;
 //   T          from G = V^T V (MFMA tile kernel, split-K over the rows) by the dlarft recurrence in one wave;
 //   trailing   A2 -= V (T^T (V^T A2)) as three products on the tile kernel.
 // dorgqr applies the block reflectors, last panel first, to [I; 0] in workspace and copies the result over A.
-// HBM-bound per column (the panel is re-read twice per column); dlarfg's rescaling loop for subnormal norms is omitted.
+// HBM-bound per column (the rest of the panel is read and written once per column); dlarfg's rescaling loop for subnormal
+// norms is omitted.
 #include "capi_internal.h"
 
 namespace {
@@ -107,6 +109,96 @@ __global__ void panel_apply_kernel(double* __restrict__ a, int64_t lda, int64_t 
   }
 }
 
+// ---- fused panel: ONE pass over the rest of the panel per column ---------------------------------------------------
+// State between columns: part[b][0] = partial sum of x^2, part[b][1 + t] = partial sum of x * A[:, t-th column right of x],
+// for the UNSCALED x = A[j+1:, j] of the column about to be reduced.  reflector_w_kernel turns them into beta, tau, the
+// scale of x and w = tau v^T A (v = [1; x * scal]: v^T A_c = A[j][c] + scal * x^T A_c[j+1:]); panel_pass_kernel scales x,
+// applies the rank-1 update to the remaining columns and, on the updated values, accumulates the same partial sums for the
+// next column.  Partial sums live in fixed slots and are added in a fixed order: bit-reproducible.
+template <int DUMMY = 0>
+__device__ __forceinline__ void store_block_sums(const double (&acc)[QNB], int count, double* __restrict__ out, double* red) {
+#pragma unroll
+  for (int c = 0; c < QNB; ++c) {
+    if (c < count) {
+      const double t = block_sum(acc[c], red);
+      if (threadIdx.x == 0) out[c] = t;
+    }
+  }
+}
+
+// a = &A[j][j]; nc columns right of it; sw[0] = scal, sw[1 + c] = w[c]; tau_j = &tau[j]
+__global__ void reflector_w_kernel(double* __restrict__ a, int64_t lda, int64_t len, int nc, const double* __restrict__ part, int npart,
+                                   double* __restrict__ tau_j, double* __restrict__ sw) {
+  __shared__ double sums[QNB];
+  __shared__ double sc[2];                                   // scal, tau
+  const int t = threadIdx.x;
+  if (t <= nc) {
+    double s = 0.0;
+    if (len > 0)
+      for (int b = 0; b < npart; ++b) s += part[(int64_t)b * QNB + t];
+    sums[t] = s;
+  }
+  __syncthreads();
+  if (t == 0) {
+    const double xnorm2 = sums[0], alpha = a[0];
+    double scal = 0.0, tv = 0.0;
+    if (xnorm2 != 0.0) {
+      const double nrm = sqrt(alpha * alpha + xnorm2);
+      const double beta = alpha >= 0.0 ? -nrm : nrm;
+      scal = 1.0 / (alpha - beta);
+      tv = (beta - alpha) / beta;
+      a[0] = beta;
+    }
+    *tau_j = tv;
+    sc[0] = scal; sc[1] = tv;
+    sw[0] = scal;
+  }
+  __syncthreads();
+  if (t >= 1 && t <= nc) sw[t] = sc[1] * (a[(int64_t)t * lda] + sc[0] * sums[t]);   // w[t-1] = tau (A[j][c] + scal x^T A_c)
+}
+
+// APPLY: scale x (rows 1.. of column 0 of `a`), update columns 1..nc, accumulate the next column's partial sums (its x starts
+// two rows below a's first row).  !APPLY: only accumulate, for column 0 itself (first column of a panel; x starts at row 1).
+template <bool APPLY>
+__global__ void panel_pass_kernel(double* __restrict__ a, int64_t lda, int64_t rows, int nc, const double* __restrict__ sw,
+                                  double* __restrict__ part) {
+  __shared__ double red[4];
+  double acc[QNB];
+#pragma unroll
+  for (int c = 0; c < QNB; ++c) acc[c] = 0.0;
+  double wl[QNB - 1];
+  double scal = 0.0;
+  if (APPLY) {
+    scal = sw[0];
+#pragma unroll
+    for (int c = 0; c < QNB - 1; ++c) wl[c] = c < nc ? sw[1 + c] : 0.0;
+  }
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (int64_t)gridDim.x * 256) {
+    if (APPLY) {
+      double v = 1.0;
+      if (r > 0) { v = a[r] * scal; a[r] = v; }
+      double x = 0.0;
+#pragma unroll
+      for (int c = 0; c < QNB - 1; ++c) {
+        if (c < nc) {
+          const double val = a[r + (int64_t)(c + 1) * lda] - v * wl[c];
+          a[r + (int64_t)(c + 1) * lda] = val;
+          if (c == 0) { x = r >= 2 ? val : 0.0; acc[0] += x * x; }
+          else acc[c] += x * val;
+        }
+      }
+    } else {
+      const double x = r >= 1 ? a[r] : 0.0;
+      acc[0] += x * x;
+#pragma unroll
+      for (int c = 0; c < QNB - 1; ++c)
+        if (c < nc) acc[c + 1] += x * a[r + (int64_t)(c + 1) * lda];
+    }
+  }
+  // APPLY: the next column has nc - 1 columns to its right -> nc values (norm + nc - 1 dots); !APPLY: nc + 1 values
+  store_block_sums(acc, APPLY ? nc : nc + 1, part + (int64_t)blockIdx.x * QNB, red);
+}
+
 // Vw (rows x nb, ld rows) <- the panel's reflectors: unit diagonal, zeros above, A's entries below
 __global__ void form_v_kernel(const double* __restrict__ a, int64_t lda, int64_t rows, int nb, double* __restrict__ vw) {
   const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -194,26 +286,24 @@ int capi_dgeqrf(capi_handle_t h, int64_t m, int64_t n, double* A, int64_t lda, d
   hipStream_t s = h->stream;
   for (int64_t j0 = 0; j0 < k; j0 += QNB) {
     const int nb = (int)(k - j0 < QNB ? k - j0 : QNB);
-    // panel: columns j0 .. j0+nb-1, one reflector at a time
-    for (int c = 0; c < nb; ++c) {
-      const int64_t j = j0 + c, rows = m - j, len = rows - 1;
-      double* a = A + j + j * lda;
-      const int np = nslots(len > 0 ? len : 1);
-      if (len > 0) {
-        hipLaunchKernelGGL(col_sumsq_kernel, dim3(np), dim3(256), 0, s, a + 1, len, w.part);
-        hipLaunchKernelGGL(make_reflector_kernel, dim3(np), dim3(256), 0, s, a, len, w.part, np, tau + j);
-        hipLaunchKernelGGL(set_beta_kernel, dim3(1), dim3(1), 0, s, a, w.part, np);
-      } else {
-        CAPI_HIP_CHECK(h, hipMemsetAsync(tau + j, 0, sizeof(double), s));   // last row: H = I
+    // panel: columns j0 .. j0+nb-1, one reflector at a time, one pass over the rest of the panel per column
+    {
+      double* a0 = A + j0 + j0 * lda;
+      const int np0 = nslots(m - j0);
+      hipLaunchKernelGGL(panel_pass_kernel<false>, dim3(np0), dim3(256), 0, s, a0, lda, m - j0, nb - 1, w.wv, w.part);
+      int np_prev = np0;                                      // slots the current column's partial sums occupy
+      for (int c = 0; c < nb; ++c) {
+        const int64_t j = j0 + c, rows = m - j, len = rows - 1;
+        double* a = A + j + j * lda;
+        const int nc = nb - 1 - c;                            // columns of the panel right of j
+        hipLaunchKernelGGL(reflector_w_kernel, dim3(1), dim3(64), 0, s, a, lda, len, nc, w.part, np_prev, tau + j, w.wv);
+        if (len > 0) {
+          const int np2 = nslots(rows);
+          hipLaunchKernelGGL(panel_pass_kernel<true>, dim3(np2), dim3(256), 0, s, a, lda, rows, nc, w.wv, w.part);
+          np_prev = np2;
+        }
+        CAPI_HIP_CHECK(h, hipGetLastError());
       }
-      const int nc = nb - 1 - c;                              // columns of the panel right of j
-      if (nc > 0) {
-        const int np2 = nslots(rows);
-        hipLaunchKernelGGL(panel_dot_kernel, dim3(np2), dim3(256), 0, s, a, lda, rows, nc, w.part);
-        hipLaunchKernelGGL(reduce_w_kernel, dim3(1), dim3(QNB), 0, s, w.part, np2, nc, tau + j, w.wv);
-        hipLaunchKernelGGL(panel_apply_kernel, dim3(np2), dim3(256), 0, s, a, lda, rows, nc, w.wv);
-      }
-      CAPI_HIP_CHECK(h, hipGetLastError());
     }
     // trailing block A2 = A[j0:m, j0+nb:n]:  A2 <- (I - V T^T V^T) A2
     const int64_t n2 = n - j0 - nb, rows = m - j0;

@@ -129,17 +129,27 @@ __device__ __forceinline__ void store_block_sums(const double (&acc)[QNB], int c
 // a = &A[j][j]; nc columns right of it; sw[0] = scal, sw[1 + c] = w[c]; tau_j = &tau[j]
 __global__ void reflector_w_kernel(double* __restrict__ a, int64_t lda, int64_t len, int nc, const double* __restrict__ part, int npart,
                                    double* __restrict__ tau_j, double* __restrict__ sw) {
+  // 256 threads = 32 values x 8 slot-lanes: lane g sums slots g, g + 8, ... (loads independent of each other), the eight
+  // partial sums are added in a fixed order
+  __shared__ double ps[8][QNB];
   __shared__ double sums[QNB];
   __shared__ double sc[2];                                   // scal, tau
-  const int t = threadIdx.x;
-  if (t <= nc) {
+  const int t = threadIdx.x & (QNB - 1), g = threadIdx.x / QNB;
+  {
     double s = 0.0;
-    if (len > 0)
-      for (int b = 0; b < npart; ++b) s += part[(int64_t)b * QNB + t];
+    if (t <= nc && len > 0)
+      for (int b = g; b < npart; b += 8) s += part[(int64_t)b * QNB + t];
+    ps[g][t] = s;
+  }
+  __syncthreads();
+  if (g == 0) {
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += ps[q][t];
     sums[t] = s;
   }
   __syncthreads();
-  if (t == 0) {
+  if (threadIdx.x == 0) {
     const double xnorm2 = sums[0], alpha = a[0];
     double scal = 0.0, tv = 0.0;
     if (xnorm2 != 0.0) {
@@ -154,7 +164,7 @@ __global__ void reflector_w_kernel(double* __restrict__ a, int64_t lda, int64_t 
     sw[0] = scal;
   }
   __syncthreads();
-  if (t >= 1 && t <= nc) sw[t] = sc[1] * (a[(int64_t)t * lda] + sc[0] * sums[t]);   // w[t-1] = tau (A[j][c] + scal x^T A_c)
+  if (g == 0 && t >= 1 && t <= nc) sw[t] = sc[1] * (a[(int64_t)t * lda] + sc[0] * sums[t]);   // w[t-1] = tau (A[j][c] + scal x^T A_c)
 }
 
 // APPLY: scale x (rows 1.. of column 0 of `a`), update columns 1..nc, accumulate the next column's partial sums (its x starts
@@ -296,7 +306,7 @@ int capi_dgeqrf(capi_handle_t h, int64_t m, int64_t n, double* A, int64_t lda, d
         const int64_t j = j0 + c, rows = m - j, len = rows - 1;
         double* a = A + j + j * lda;
         const int nc = nb - 1 - c;                            // columns of the panel right of j
-        hipLaunchKernelGGL(reflector_w_kernel, dim3(1), dim3(64), 0, s, a, lda, len, nc, w.part, np_prev, tau + j, w.wv);
+        hipLaunchKernelGGL(reflector_w_kernel, dim3(1), dim3(256), 0, s, a, lda, len, nc, w.part, np_prev, tau + j, w.wv);
         if (len > 0) {
           const int np2 = nslots(rows);
           hipLaunchKernelGGL(panel_pass_kernel<true>, dim3(np2), dim3(256), 0, s, a, lda, rows, nc, w.wv, w.part);

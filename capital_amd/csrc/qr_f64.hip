@@ -17,7 +17,7 @@
 namespace {
 
 constexpr int QNB = 32;      // block reflector width
-constexpr int QPART = 512;   // partial-sum slots of the column reductions
+constexpr int QPART = 1024;  // partial-sum slots of the column reductions (= workgroups of a panel pass: 4 per CU)
 
 __device__ __forceinline__ double block_sum(double v, double* red) {   // sum over a 256-thread workgroup, fixed order
 #pragma unroll
@@ -245,7 +245,7 @@ __global__ void identity_kernel(double* __restrict__ Q, int64_t m, int64_t n) {
 #define RC(x) do { int rc__ = (x); if (rc__ != CAPI_OK) return rc__; } while (0)
 
 int nslots(int64_t rows) {
-  int64_t b = cdiv(rows, 2048);
+  int64_t b = cdiv(rows, 1024);
   return (int)(b < 1 ? 1 : (b > QPART ? QPART : b));
 }
 

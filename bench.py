@@ -60,7 +60,7 @@ def cpu_baseline(n_sample):
 
 
 def recorded_traffic(n, gpus):
-    """L2-to-fabric bytes per launch of the roofline kernel from the committed PMC passes (FETCH_SIZE + WRITE_SIZE, x2 on
+    """L2-to-fabric bytes per launch of the roofline kernel from the committed PMC passes (2 x FETCH_SIZE + WRITE_SIZE on
     gfx950; profiles/README.md).  Counters cannot be read from inside a timed run, so this is the last recorded
     measurement of the same configuration, or None.  The passes ran `bench.py --steps 1 --warmup 0`: every row but the
     last (the residual check's product) is a launch of the one factor() call."""
@@ -73,12 +73,13 @@ def recorded_traffic(n, gpus):
             rows = [r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", f"r1_d_pmc_{tag}_bench_step.csv"))) if r["Counter_Name"] == name]
             rows = rows[:-1]
             launches = len(rows)
-            tot += sum(float(r["Counter_Value"]) for r in rows) * 1024 * 2      # KB, 128-B requests counted at 64 B
+            # KB; gfx950 tallies a 128-B read request at 64 B (double FETCH_SIZE), WRITE_SIZE reads exactly (MI355X_MICROARCH.md)
+            tot += sum(float(r["Counter_Value"]) for r in rows) * 1024 * (2 if name == "FETCH_SIZE" else 1)
     except (OSError, KeyError, ValueError):
         return None, None
     if not launches:
         return None, None
-    return tot / launches, f"profiles/r1_d_pmc_{{fe,wr}}_bench_step.csv: FETCH_SIZE+WRITE_SIZE x2, mean of the {launches} launches of one factor()"
+    return tot / launches, f"profiles/r1_d_pmc_{{fe,wr}}_bench_step.csv: 2 x FETCH_SIZE + WRITE_SIZE, mean of the {launches} launches of one factor()"
 
 
 def main():

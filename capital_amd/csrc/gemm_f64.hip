@@ -1209,10 +1209,31 @@ __device__ __forceinline__ void trmm_ts32_body(const GemmArgs& p, double* __rest
     double* c1_ = p.C + i + (int64_t)(16 * SB + g) * p.ldc;
     const int64_t s4 = 4 * p.ldc;
     if (STEADY) {
+      // 16-byte stores: lanes 2k and 2k+1 hold rows 2k, 2k+1 of the same columns, so a pair of registers (columns a, b) is
+      // traded across the lane pair -- the even lane ends with rows 2k, 2k+1 of column a, the odd lane with those of column b.
+      // (With 8-byte-per-lane stores WRITE_SIZE counted twice the bytes stored: the lines reached the fabric in halves.)
+      const bool odd = lane & 1;
+      auto swap1 = [](double v) {
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xF, 0xF, false);
+        return __hiloint2double(hi, lo);
+      };
+      auto put2 = [&](double* base, double va, double vb) {   // base: row 2k (this lane pair), column of register a; b = a + 4 columns
+        const double give = odd ? va : vb;
+        const double got = swap1(give);
+        d2_t out;
+        out.x = odd ? got : va;
+        out.y = odd ? vb : got;
+        TS_STORE((d2_t*)(base + (odd ? s4 : 0)), out);
+      };
+      double* e0 = c0_ - (lane & 1);                         // row 2k of this lane pair
+      double* e1 = c1_ - (lane & 1);
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        TS_STORE(&c0_[reg * s4], p.alpha * ca0[reg]); TS_STORE(&c0_[reg * s4 + 16], p.alpha * ca1[reg]);
-        TS_STORE(&c1_[reg * s4], p.alpha * cb0[reg]); TS_STORE(&c1_[reg * s4 + 16], p.alpha * cb1[reg]);
+      for (int pr = 0; pr < 2; ++pr) {                       // register pairs (0,1) and (2,3): columns g + 8 pr and g + 8 pr + 4
+        put2(e0 + 2 * pr * s4, p.alpha * ca0[2 * pr], p.alpha * ca0[2 * pr + 1]);
+        put2(e0 + 2 * pr * s4 + 16, p.alpha * ca1[2 * pr], p.alpha * ca1[2 * pr + 1]);
+        put2(e1 + 2 * pr * s4, p.alpha * cb0[2 * pr], p.alpha * cb0[2 * pr + 1]);
+        put2(e1 + 2 * pr * s4 + 16, p.alpha * cb1[2 * pr], p.alpha * cb1[2 * pr + 1]);
       }
     } else {
       const bool ok0 = i < p.M, ok1 = i + 16 < p.M;
@@ -1238,7 +1259,7 @@ __device__ __forceinline__ void trmm_ts32_body(const GemmArgs& p, double* __rest
   stage(lds, t0, st);
   __syncthreads();
   int tile = t0;
-  if (p.a_vec && p.beta == 0.0) {
+  if (p.a_vec && p.beta == 0.0 && (((uintptr_t)p.C & 15) == 0) && ((p.ldc & 1) == 0)) {   // (16-byte stores of row pairs)
     const int nfull = p.M >> 5;                             // tiles with all 32 rows
     for (; tile + dt < nfull; tile += dt) step(tile, std::true_type{});
   }

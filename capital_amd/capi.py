@@ -77,6 +77,9 @@ _COMM_SIGS = {
     "capi_reduce_sum": [_vp, _vp, _vp, _i64, _int],
     "capi_allgather": [_vp, _vp, _vp, _i64],
     "capi_sendrecv_replace": [_vp, _vp, _i64, _int, _vp],
+    "capi_gather": [_vp, _vp, _vp, _i64, _int],
+    "capi_scatter": [_vp, _vp, _vp, _i64, _int],
+    "capi_comm_query": [_vp, C.POINTER(_int), C.POINTER(_int)],
 }
 
 _lib = None

@@ -1,5 +1,7 @@
 // capi_core.hip -- handle lifecycle, device memory, workspace, timers.
 // Replaces the host new[]/memcpy/memset inside matrix<> (reference src/matrix/structure.hpp:4-26).
+#include <dlfcn.h>
+#include <stdlib.h>
 #include "capi_internal.h"
 
 extern "C" {
@@ -12,10 +14,7 @@ int capi_device_count(void) {
   return n;
 }
 
-static int capi_create_common(capi_handle_t* out, int device, void* stream, bool own) {
-  if (!out) return CAPI_EINVAL;
-  capi_handle_s* h = new capi_handle_s();
-  h->device = device;
+static int capi_create_fill(capi_handle_s* h, int device, void* stream, bool own) {
   CAPI_HIP_CHECK(h, hipSetDevice(device));
   if (own) {
     // the handle's own compute stream carries the factorisation's latency-bound chain: highest priority, so that its
@@ -35,6 +34,20 @@ static int capi_create_common(capi_handle_t* out, int device, void* stream, bool
   hipDeviceProp_t prop;
   CAPI_HIP_CHECK(h, hipGetDeviceProperties(&prop, device));
   h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  return CAPI_OK;
+}
+
+static int capi_create_common(capi_handle_t* out, int device, void* stream, bool own) {
+  if (!out) return CAPI_EINVAL;
+  *out = nullptr;
+  capi_handle_s* h = new capi_handle_s();
+  h->device = device;
+  int rc = capi_create_fill(h, device, stream, own);
+  if (rc != CAPI_OK) {          // whatever was created so far goes away with the half-built handle
+    fprintf(stderr, "capi_create: %s\n", h->err);
+    capi_destroy(h);
+    return rc;
+  }
   *out = h;
   return CAPI_OK;
 }
@@ -60,7 +73,7 @@ int capi_destroy(capi_handle_t h) {
   free(h->prof);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
-  if (h->owns_stream) (void)hipStreamDestroy(h->stream);
+  if (h->owns_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return CAPI_OK;
 }
@@ -197,6 +210,44 @@ int capi_timer_stop_ms(capi_handle_t h, float* ms) {
   CAPI_HIP_CHECK(h, hipEventRecord(h->ev1, h->stream));
   CAPI_HIP_CHECK(h, hipEventSynchronize(h->ev1));
   CAPI_HIP_CHECK(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+  return CAPI_OK;
+}
+
+
+// ---- phase markers: the reference's CRITTER_START/STOP regions (src/util/shared.h:26-35) as roctx ranges, so that
+// `rocprofv3 --marker-trace` attributes a step to CI::factor_diag / CI::trsm / CI::tmu / CQR::gram / CQR::formR.  The roctx
+// library is bound on first use (rocprofiler-sdk's, which rocprofv3 intercepts; roctracer's as a fallback); without
+// either, or with CAPI_NO_MARKERS set, the calls cost one predictable branch.
+namespace {
+struct RoctxApi {
+  bool tried = false;
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+} g_roctx;
+void roctx_bind() {
+  g_roctx.tried = true;
+  if (getenv("CAPI_NO_MARKERS")) return;
+  const char* names[] = {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "/opt/rocm/lib/librocprofiler-sdk-roctx.so",
+                         "libroctx64.so.4", "/opt/rocm/lib/libroctx64.so.4"};
+  for (const char* nm : names) {
+    void* lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) continue;
+    *(void**)(&g_roctx.push) = dlsym(lib, "roctxRangePushA");
+    *(void**)(&g_roctx.pop) = dlsym(lib, "roctxRangePop");
+    if (g_roctx.push && g_roctx.pop) return;
+    g_roctx.push = nullptr; g_roctx.pop = nullptr;
+  }
+}
+}  // namespace
+
+int capi_range_push(const char* name) {
+  if (!g_roctx.tried) roctx_bind();
+  if (g_roctx.push && name) g_roctx.push(name);
+  return CAPI_OK;
+}
+int capi_range_pop(void) {
+  if (!g_roctx.tried) roctx_bind();
+  if (g_roctx.pop) g_roctx.pop();
   return CAPI_OK;
 }
 

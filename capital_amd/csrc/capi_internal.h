@@ -34,8 +34,21 @@ struct capi_handle_s {
   struct prof_rec { hipEvent_t e0, e1; double flops; int variant; };
   prof_rec* prof = nullptr;
   int prof_n = 0, prof_cap = 0;
+  // kernels whose dynamic-LDS limit has been raised on THIS handle's device (hipFuncSetAttribute is per device; a
+  // process-wide flag would leave a second device's copy of the kernel at the default limit)
+  uint32_t lds_attr_done = 0;
   char err[512] = {0};
 };
+
+enum { CAPI_ATTR_LEAF = 0, CAPI_ATTR_TRMM_TS32 = 1, CAPI_ATTR_TRMM_TS16 = 2, CAPI_ATTR_GRAM_TS = 3, CAPI_ATTR_SMALL0 = 4 /* ..7 */,
+       CAPI_ATTR_GRAM_WIDE = 8, CAPI_ATTR_TRMM_WIDE = 9 };
+#define CAPI_RAISE_LDS_LIMIT(h, bit, fn, bytes)                                                                    \
+  do {                                                                                                             \
+    if (!((h)->lds_attr_done & (1u << (bit)))) {                                                                   \
+      CAPI_HIP_CHECK(h, hipFuncSetAttribute((const void*)(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); \
+      (h)->lds_attr_done |= 1u << (bit);                                                                           \
+    }                                                                                                              \
+  } while (0)
 
 #define CAPI_HIP_CHECK(h, call)                                                              \
   do {                                                                                       \

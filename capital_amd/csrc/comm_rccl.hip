@@ -21,6 +21,8 @@ struct RcclApi {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommSplit)(ncclComm_t, int, int, ncclComm_t*, ncclConfig_t*) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -52,6 +54,8 @@ int rccl_bind(const char* path) {
   BIND(CommInitRank, "ncclCommInitRank")
   BIND(CommSplit, "ncclCommSplit")
   BIND(CommDestroy, "ncclCommDestroy")
+  BIND(CommUserRank, "ncclCommUserRank")
+  BIND(CommCount, "ncclCommCount")
   BIND(Broadcast, "ncclBroadcast")
   BIND(AllReduce, "ncclAllReduce")
   BIND(Reduce, "ncclReduce")
@@ -94,36 +98,54 @@ int capi_comm_unique_id(void* id128) {
 
 int capi_comm_init_rank(capi_comm_t* out, capi_handle_t h, int nranks, const void* id128, int rank) {
   CAPI_REQUIRE(h, h && out && nranks >= 1 && rank >= 0 && rank < nranks, "args");
+  *out = nullptr;
   capi_comm_s* c = new capi_comm_s();
   c->h = h;
   c->rank = rank;
   c->size = nranks;
+  // every failure below releases the object: a caller that retries must not accumulate half-built communicators
+  auto fail = [&](int rc) { delete c; return rc; };
   if (nranks > 1 || getenv("CAPI_RCCL_FORCE")) {
-    CAPI_REQUIRE(h, id128, "unique id");
+    if (!id128) { snprintf(h->err, sizeof(h->err), "capi_comm_init_rank: unique id missing"); return fail(CAPI_EINVAL); }
     int rc = rccl_bind(nullptr);
-    if (rc != CAPI_OK) { snprintf(h->err, sizeof(h->err), "%s", g_rccl_err); delete c; return rc; }
-    CAPI_HIP_CHECK(h, hipSetDevice(h->device));
+    if (rc != CAPI_OK) { snprintf(h->err, sizeof(h->err), "%s", g_rccl_err); return fail(rc); }
+    hipError_t e = hipSetDevice(h->device);
+    if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "hipSetDevice -> %s", hipGetErrorString(e)); return fail(CAPI_EHIP); }
     ncclUniqueId id;
     memcpy(&id, id128, sizeof(id));
-    NCCL_CHECK(c, g_rccl.CommInitRank(&c->comm, nranks, id, rank));
+    ncclResult_t r = g_rccl.CommInitRank(&c->comm, nranks, id, rank);
+    if (r != ncclSuccess) { snprintf(h->err, sizeof(h->err), "ncclCommInitRank -> %s", g_rccl.GetErrorString(r)); return fail(CAPI_ECOMM); }
   }
   *out = c;
   return CAPI_OK;
 }
 
+// MPI_Comm_split.  A negative colour is MPI_UNDEFINED / NCCL_SPLIT_NOCOLOR: the rank takes part in the call (it is
+// collective over the parent) and receives no communicator -- *child = NULL with status OK.
 int capi_comm_split(capi_comm_t parent, int color, int key, capi_comm_t* child) {
   if (!parent || !child) return CAPI_EINVAL;
-  capi_comm_s* c = new capi_comm_s();
-  c->h = parent->h;
+  *child = nullptr;
   if (!parent->comm) {
+    if (color < 0) return CAPI_OK;
+    capi_comm_s* c = new capi_comm_s();
+    c->h = parent->h;
     c->rank = 0;
     c->size = 1;
-  } else {
-    NCCL_CHECK(parent, g_rccl.CommSplit(parent->comm, color, key, &c->comm, nullptr));
-    // rank/size of the child: RCCL orders by key then parent rank; recover them from the library
-    int (*cu)(const ncclComm_t, int*) = (int (*)(const ncclComm_t, int*))dlsym(g_rccl.lib, "ncclCommUserRank");
-    int (*cc)(const ncclComm_t, int*) = (int (*)(const ncclComm_t, int*))dlsym(g_rccl.lib, "ncclCommCount");
-    if (!cu || !cc || cu(c->comm, &c->rank) != 0 || cc(c->comm, &c->size) != 0) return CAPI_ECOMM;
+    *child = c;
+    return CAPI_OK;
+  }
+  ncclComm_t sub = nullptr;
+  NCCL_CHECK(parent, g_rccl.CommSplit(parent->comm, color < 0 ? NCCL_SPLIT_NOCOLOR : color, key, &sub, nullptr));
+  if (color < 0 || !sub) return CAPI_OK;
+  capi_comm_s* c = new capi_comm_s();
+  c->h = parent->h;
+  c->comm = sub;
+  // rank/size of the child: RCCL orders by key then parent rank; recover them from the library
+  if (g_rccl.CommUserRank(sub, &c->rank) != ncclSuccess || g_rccl.CommCount(sub, &c->size) != ncclSuccess) {
+    snprintf(parent->h->err, sizeof(parent->h->err), "capi_comm_split: ncclCommUserRank/ncclCommCount failed on the child");
+    g_rccl.CommDestroy(sub);
+    delete c;
+    return CAPI_ECOMM;
   }
   *child = c;
   return CAPI_OK;
@@ -132,10 +154,24 @@ int capi_comm_split(capi_comm_t parent, int color, int key, capi_comm_t* child) 
 int capi_comm_rank(capi_comm_t c, int* rank) { if (!c || !rank) return CAPI_EINVAL; *rank = c->rank; return CAPI_OK; }
 int capi_comm_size(capi_comm_t c, int* size) { if (!c || !size) return CAPI_EINVAL; *size = c->size; return CAPI_OK; }
 
+// what the LIBRARY reports for this communicator (a launcher prints it next to its own idea of rank and size);
+// a communicator of one rank that never touched RCCL reports itself
+int capi_comm_query(capi_comm_t c, int* rank, int* size) {
+  if (!c || !rank || !size) return CAPI_EINVAL;
+  *rank = c->rank; *size = c->size;
+  if (c->comm) {
+    NCCL_CHECK(c, g_rccl.CommUserRank(c->comm, rank));
+    NCCL_CHECK(c, g_rccl.CommCount(c->comm, size));
+  }
+  return CAPI_OK;
+}
+
 int capi_comm_destroy(capi_comm_t c) {
   if (!c) return CAPI_EINVAL;
   if (c->comm) {
-    (void)hipStreamSynchronize(c->h->stream);
+    // collectives of this communicator may be in flight on ANY of the handle's streams (the chunk pipeline issues them on
+    // stream index 1): all of them are drained before the communicator goes away
+    (void)capi_sync(c->h);
     g_rccl.CommDestroy(c->comm);
   }
   delete c;
@@ -178,14 +214,64 @@ int capi_allgather(capi_comm_t c, const double* send, double* recv, int64_t coun
   return CAPI_OK;
 }
 
+// A group that was opened is always closed: the first failing call inside it is remembered and reported after GroupEnd.
+#define NCCL_IN_GROUP(c, first, call)                                                            \
+  do {                                                                                           \
+    ncclResult_t r__ = (call);                                                                   \
+    if (r__ != ncclSuccess && (first) == ncclSuccess) (first) = r__;                             \
+  } while (0)
+static int group_result(capi_comm_t c, ncclResult_t first, const char* what) {
+  ncclResult_t e = g_rccl.GroupEnd();
+  if (first == ncclSuccess) first = e;
+  if (first != ncclSuccess) {
+    snprintf(c->h->err, sizeof(c->h->err), "%s -> %s", what, g_rccl.GetErrorString(first));
+    return CAPI_ECOMM;
+  }
+  return CAPI_OK;
+}
+
+// MPI_Gather / MPI_Scatter of `count` doubles per rank (cholinv/policy.h:322-332,361-377): RCCL has neither, both are one
+// group of point-to-point calls -- on the xGMI mesh every peer of the root is a link of its own.
+int capi_gather(capi_comm_t c, const double* send, double* recv, int64_t count, int root) {
+  if (!c || count < 0 || root < 0 || root >= c->size) return CAPI_EINVAL;
+  if (count == 0) return CAPI_OK;
+  if (!c->comm) {
+    if (send != recv) CAPI_HIP_CHECK(c->h, hipMemcpyAsync(recv, send, sizeof(double) * count, hipMemcpyDeviceToDevice, c->h->stream));
+    return CAPI_OK;
+  }
+  NCCL_CHECK(c, g_rccl.GroupStart());
+  ncclResult_t first = ncclSuccess;
+  NCCL_IN_GROUP(c, first, g_rccl.Send(send, (size_t)count, ncclDouble, root, c->comm, c->h->stream));
+  if (c->rank == root)
+    for (int r = 0; r < c->size; ++r) NCCL_IN_GROUP(c, first, g_rccl.Recv(recv + (int64_t)r * count, (size_t)count, ncclDouble, r, c->comm, c->h->stream));
+  return group_result(c, first, "capi_gather");
+}
+
+int capi_scatter(capi_comm_t c, const double* send, double* recv, int64_t count, int root) {
+  if (!c || count < 0 || root < 0 || root >= c->size) return CAPI_EINVAL;
+  if (count == 0) return CAPI_OK;
+  if (!c->comm) {
+    if (send != recv) CAPI_HIP_CHECK(c->h, hipMemcpyAsync(recv, send, sizeof(double) * count, hipMemcpyDeviceToDevice, c->h->stream));
+    return CAPI_OK;
+  }
+  NCCL_CHECK(c, g_rccl.GroupStart());
+  ncclResult_t first = ncclSuccess;
+  if (c->rank == root)
+    for (int r = 0; r < c->size; ++r) NCCL_IN_GROUP(c, first, g_rccl.Send(send + (int64_t)r * count, (size_t)count, ncclDouble, r, c->comm, c->h->stream));
+  NCCL_IN_GROUP(c, first, g_rccl.Recv(recv, (size_t)count, ncclDouble, root, c->comm, c->h->stream));
+  return group_result(c, first, "capi_scatter");
+}
+
 int capi_sendrecv_replace(capi_comm_t c, double* buf, int64_t count, int peer, double* staging) {
   if (!c || count < 0 || peer < 0 || peer >= c->size) return CAPI_EINVAL;
   if (count == 0 || (peer == c->rank && !(c->comm && c->size == 1))) return CAPI_OK;   // (forced 1-rank communicator: a real self send/recv)
   if (!staging) return CAPI_EINVAL;
   NCCL_CHECK(c, g_rccl.GroupStart());
-  NCCL_CHECK(c, g_rccl.Send(buf, (size_t)count, ncclDouble, peer, c->comm, c->h->stream));
-  NCCL_CHECK(c, g_rccl.Recv(staging, (size_t)count, ncclDouble, peer, c->comm, c->h->stream));
-  NCCL_CHECK(c, g_rccl.GroupEnd());
+  ncclResult_t first = ncclSuccess;
+  NCCL_IN_GROUP(c, first, g_rccl.Send(buf, (size_t)count, ncclDouble, peer, c->comm, c->h->stream));
+  NCCL_IN_GROUP(c, first, g_rccl.Recv(staging, (size_t)count, ncclDouble, peer, c->comm, c->h->stream));
+  int rc = group_result(c, first, "capi_sendrecv_replace");
+  if (rc != CAPI_OK) return rc;
   CAPI_HIP_CHECK(c->h, hipMemcpyAsync(buf, staging, sizeof(double) * count, hipMemcpyDeviceToDevice, c->h->stream));
   return CAPI_OK;
 }

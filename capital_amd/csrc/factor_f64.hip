@@ -490,11 +490,7 @@ int leaf_launch(capi_handle_t h, double* A, int64_t lda, double* X, int64_t ldx,
       blocks += (unsigned)(want < 192 ? want : 192);
     }
     const size_t lds_bytes = sizeof(double) * (LB * LLD + LNT * 256 + 4 * 16);
-    static bool attr_set = false;
-    if (!attr_set) {
-      CAPI_HIP_CHECK(h, hipFuncSetAttribute((const void*)potrf_trtri_leaf128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-      attr_set = true;
-    }
+    CAPI_RAISE_LDS_LIMIT(h, CAPI_ATTR_LEAF, potrf_trtri_leaf128_kernel, lds_bytes);
     static const bool trace = getenv("CAPI_LEAF_TRACE") != nullptr;
     long long* dbg = nullptr;
     if (trace) CAPI_HIP_CHECK(h, hipMalloc((void**)&dbg, sizeof(long long) * 64));

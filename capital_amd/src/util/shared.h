@@ -22,10 +22,17 @@
 
 #include "capital_hip.h"
 
-// Region markers of the reference's external profiler (shared.h:26-35) are kept as no-op hooks.
+// Region markers of the reference's external profiler (shared.h:26-35: CRITTER_START(sym) / CRITTER_STOP(sym) around the
+// algorithmic phases CI::factor_diag, CI::trsm, CI::tmu, CQR::gram, CQR::formR) become roctx ranges with the same names:
+// `rocprofv3 --marker-trace` then attributes a step to its phases.  -DCAPITAL_NO_MARKERS compiles them out.
 #ifndef CRITTER_START
+#ifdef CAPITAL_NO_MARKERS
 #define CRITTER_START(ARG)
 #define CRITTER_STOP(ARG)
+#else
+#define CRITTER_START(ARG) capi_range_push(#ARG)
+#define CRITTER_STOP(ARG) capi_range_pop()
+#endif
 #endif
 
 namespace capital {

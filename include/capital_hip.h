@@ -151,7 +151,8 @@ int capi_diff_norms(capi_handle_t h, int part, int64_t m, int64_t n, const doubl
 int capi_comm_load_rccl(const char* librccl_path);              /* optional: choose the librccl.so to bind (default: search) */
 int capi_comm_unique_id(void* id128);
 int capi_comm_init_rank(capi_comm_t* comm, capi_handle_t h, int nranks, const void* id128, int rank);
-int capi_comm_split(capi_comm_t parent, int color, int key, capi_comm_t* child);       /* MPI_Comm_split, topology.h:28-59,84-138 */
+int capi_comm_split(capi_comm_t parent, int color, int key, capi_comm_t* child);       /* MPI_Comm_split, topology.h:28-59,84-138; color < 0 = MPI_UNDEFINED: *child = NULL */
+int capi_comm_query(capi_comm_t c, int* rank, int* size);                              /* rank and size as RCCL itself reports them */
 int capi_comm_rank(capi_comm_t c, int* rank);
 int capi_comm_size(capi_comm_t c, int* size);
 int capi_comm_destroy(capi_comm_t c);
@@ -160,6 +161,9 @@ int capi_allreduce_sum(capi_comm_t c, double* buf, int64_t count);              
 int capi_reduce_sum(capi_comm_t c, const double* send, double* recv, int64_t count, int root);  /* MPI_Reduce, cacqr.hpp:98 */
 int capi_allgather(capi_comm_t c, const double* send, double* recv, int64_t count_per_rank);   /* MPI_Allgather, policy.h:176 */
 int capi_sendrecv_replace(capi_comm_t c, double* buf, int64_t count, int peer, double* staging); /* MPI_Sendrecv_replace, util.hpp:240 */
+/* root collects / deals `count_per_rank` doubles per rank, rank r's piece at recv/send + r*count (one group of RCCL send/recv) */
+int capi_gather(capi_comm_t c, const double* send, double* recv, int64_t count_per_rank, int root);   /* MPI_Gather, cholinv/policy.h:322-332 */
+int capi_scatter(capi_comm_t c, const double* send, double* recv, int64_t count_per_rank, int root);  /* MPI_Scatter / MPI_Iscatter, policy.h:361-377,470-488 */
 
 /* ---- extra streams + events: lets the host layer run collectives beside the tile kernel (the reference's
  *      MPI_Ibcast/Iallreduce chunk pipeline, summa.hpp:195-215,238-249) and the bulk of a trailing update beside the
@@ -180,6 +184,10 @@ int capi_mfma_f64_peak(capi_handle_t h, int iters, double* tflops);
  * alone, i.e. one kernel symbol; -1 = all variants). */
 int capi_prof_enable(capi_handle_t h, int on);
 int capi_prof_collect(capi_handle_t h, int variant, int64_t* launches, double* total_ms, double* total_flops, double* max_ms);
+/* phase markers: the reference's CRITTER_START/STOP(sym) regions (src/util/shared.h:26-35; cholinv.hpp:94-158, cacqr.hpp:82-116)
+ * as roctx ranges for `rocprofv3 --marker-trace`; no-ops when no roctx library can be bound */
+int capi_range_push(const char* name);
+int capi_range_pop(void);
 /* HIP-event timer on the handle's stream */
 int capi_timer_start(capi_handle_t h);
 int capi_timer_stop_ms(capi_handle_t h, float* ms);              /* synchronises */

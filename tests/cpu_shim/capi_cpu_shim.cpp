@@ -216,6 +216,8 @@ int capi_comm_split(capi_comm_t parent, int color, int key, capi_comm_t* child) 
   std::vector<double> mine = {(double)color, (double)key}, all((size_t)2 * n);
   if (n == 1) all = mine;
   else if (coll(parent, 3, mine.data(), all.data(), 2, 0)) return CAPI_ECOMM;
+  *child = nullptr;
+  if (color < 0) return 0;                                   // MPI_UNDEFINED: took part in the exchange, gets no communicator
   capi_comm_s* c = new capi_comm_s();
   c->h = parent->h;
   std::vector<std::pair<std::pair<int, int>, int>> members;  // ((key, parent index), world rank)
@@ -239,6 +241,27 @@ int capi_allgather(capi_comm_t c, const double* send, double* recv, int64_t coun
   if (c->ranks.size() == 1) { if (send != recv) memmove(recv, send, sizeof(double) * count); return 0; }
   return coll(c, 3, (double*)send, recv, count, 0);
 }
+// gather / scatter ride on the callback's allgather and bcast (the shim has no point-to-point op of its own)
+int capi_gather(capi_comm_t c, const double* send, double* recv, int64_t count, int root) {
+  const size_t n = c->ranks.size();
+  if (n == 1) { if (send != recv) memmove(recv, send, sizeof(double) * count); return 0; }
+  std::vector<double> all(n * (size_t)count);
+  if (coll(c, 3, (double*)send, all.data(), count, 0)) return CAPI_ECOMM;
+  if (c->me == root) memcpy(recv, all.data(), sizeof(double) * all.size());
+  return 0;
+}
+int capi_scatter(capi_comm_t c, const double* send, double* recv, int64_t count, int root) {
+  const size_t n = c->ranks.size();
+  if (n == 1) { if (send != recv) memmove(recv, send, sizeof(double) * count); return 0; }
+  std::vector<double> all(n * (size_t)count);
+  if (c->me == root) memcpy(all.data(), send, sizeof(double) * all.size());
+  if (coll(c, 0, all.data(), nullptr, (int64_t)all.size(), root)) return CAPI_ECOMM;
+  memcpy(recv, all.data() + (size_t)c->me * count, sizeof(double) * count);
+  return 0;
+}
+int capi_comm_query(capi_comm_t c, int* r, int* s) { if (!c) return CAPI_EINVAL; *r = c->me; *s = (int)c->ranks.size(); return 0; }
+int capi_range_push(const char*) { return 0; }
+int capi_range_pop(void) { return 0; }
 int capi_sendrecv_replace(capi_comm_t c, double* buf, int64_t count, int peer, double* staging) {
   (void)staging;
   if (peer == c->me || count == 0) return 0;

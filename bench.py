@@ -1,18 +1,25 @@
 """bench.py -- BASELINE.json's metric on MI355X: whole-job TFLOP/s (algorithmic n^3/3) of the recursive Cholesky
-with inverse (cholesky::cholinv<...>::factor), inputs resident in HBM, at 1/2/4/8 GPUs of one node.
+with inverse (cholesky::cholinv<...>::factor) at n = 65536, inputs resident in HBM, at 1/2/4/8 GPUs of one node.
 
   python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
 
 One "step" = one factor() call on the reference's synthetic SPD matrix (distribute_symmetric, structure.hpp:68-103).
-Per-GPU work is held fixed as N grows (n = 32768 * N^(1/3): weak scaling): N=1 is BASELINE config 2, N=8 config 4.
-The same JSON line also carries the CA-CholeskyQR2 figure (config 3 shape per GPU), the roofline of the dominant
-kernel (the k-contiguous "TN" MFMA tile kernel that runs the trailing update) measured with HIP events around every
-launch in the timed region, and the CPU oracle timed on a bounded sample.
+The matrix is the metric's own, n = 65536, at EVERY N (strong scaling): N = 1 holds it on one GPU (it fits: 139 GiB with
+both factors and the packed copies), N = 8 is BASELINE config 4 (2 x 2 x 2 grid).
+The same JSON line also carries
+  * `config2`: n = 32768 on one GPU (BASELINE config 2), N = 1 only;
+  * `cacqr2`: CA-CholeskyQR2 on m = 2^22 x 256 (BASELINE config 3), N = 1 only;
+  * `cacqr2_config5`: CA-CholeskyQR2 with the per-GPU slice of BASELINE config 5, 2^23 x 1024 on every GPU (m = 2^23 N:
+    weak in m; N = 8 IS config 5, m = 2^26), 4 m n^2 flops;
+  * `roofline`: the dominant kernel (the k-contiguous "TN" 128-tile MFMA kernel that runs the trailing update and the R12
+    product), HIP events around every launch of it inside the timed region, on the streams it runs on;
+  * `cpu_baseline`: the reference's schedules on the node's own host BLAS (oracle.host_baseline, its own interpreter).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -22,11 +29,13 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-FP64_MATRIX_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak per GPU (vendor figure); cross-checked by capi_mfma_f64_peak
+FP64_MATRIX_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak per GPU (vendor figure)
 
-# N -> (n, c): grid is d x d x c with d*d*c = N.  n^3/N is constant across rows (weak scaling in flops).
-CHOLESKY_GRID = {1: (32768, 1), 2: (40960, 2), 4: (51200, 1), 8: (65536, 2)}
-QR_SHAPE_PER_GPU = (1 << 22, 256)   # BASELINE config 3 on every GPU (m grows with N)
+N_CHOLESKY = 65536                # BASELINE.json `metric`: Cholesky n = 65536 -- the same matrix at every N
+GRID_C = {1: 1, 2: 2, 4: 1, 8: 2}  # N -> c of the d x d x c grid (d*d*c = N): 1x1x1, 1x1x2, 2x2x1, 2x2x2
+QR_CONFIG3 = (1 << 22, 256)       # BASELINE config 3 (one GPU)
+QR_CONFIG5_SLICE = (1 << 23, 1024)  # rows per GPU and width of BASELINE config 5 (m = 2^26 on 8 GPUs)
+BASE_CASE_ORDER = 1024            # aggregated order of the recursion's base case on every grid
 
 
 def barrier_sync(distributed):
@@ -44,42 +53,97 @@ def max_over_ranks(t, distributed, device):
     return float(v.item())
 
 
-def cpu_baseline(n_sample):
-    """The oracle (CPU restatement of the same schedule) on a bounded sample of the same workload."""
-    import oracle as O
-    O.build()
-    threads = min(os.cpu_count() or 1, 16)          # a one-GPU box's CPU share
-    O.set_threads(threads)
-    A = O.distribute_symmetric(n_sample, n_sample, 0, 0, 1, 1)
+def bc_mult_for(n, d, c, order):
+    """bc_mult_dim (cholinv.hpp:15-18: t = c d 2^|bc|, bc_loc = n_loc / t, base-case order = d bc_loc) giving `order`."""
+    n_loc = -(-n // d)
+    b = 0
+    while d * (n_loc // (c * d * (1 << (b + 1)))) >= order:
+        b += 1
+    return -b
+
+
+def cpu_baseline(n_sample, m_sample, qn):
+    """The reference's schedules with their seven BLAS/LAPACK calls bound to the host library of THIS box, all of this
+    process's cores, in a separate interpreter (no torch / HIP runtime in it).  Bounded sample of the same workload."""
+    cmd = [sys.executable, "-m", "oracle.host_baseline", "--n", str(n_sample), "--m", str(m_sample), "--qn", str(qn)]
     t0 = time.perf_counter()
-    R, Ri, info = O.cholinv_factor(A, 0, 1, -3, 1, 1)
-    dt = time.perf_counter() - t0
-    assert info == 0
-    return {"value": (n_sample ** 3 / 3.0) / dt / 1e12, "unit": "TFLOP/s", "cores": threads, "kind": "port",
-            "sample": f"n={n_sample} recursive Cholesky, same generator and schedule (bc_mult=-3), oracle/capital_oracle.c, {dt:.1f} s"}
+    try:
+        res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        js = json.loads(res.stdout.strip().splitlines()[-1])
+    except Exception as e:   # the baseline is a reported extra: its failure must not take the GPU numbers with it
+        return {"value": None, "unit": "TFLOP/s", "cores": None, "kind": "failed", "sample": f"oracle.host_baseline failed: {e!r}"[:300]}
+    ch, qr = js.get("cholesky", {}), js.get("cacqr2", {})
+    return {"value": ch.get("tflops"), "unit": "TFLOP/s", "cores": js["cores"], "kind": js["kind"], "library": js["library"],
+            "library_path": js["library_path"],
+            "sample": f"n={n_sample} recursive Cholesky with inverse (same generator and schedule, bc_mult={ch.get('bc_mult')}), "
+                      f"{ch.get('seconds', 0):.2f} s, faster of two runs; whole leg {time.perf_counter() - t0:.0f} s",
+            "cacqr2": {"value": qr.get("tflops"), "unit": "TFLOP/s", "sample": f"CholeskyQR2 m={m_sample} n={qn}, {qr.get('seconds', 0):.2f} s"}}
 
 
 def recorded_traffic(n, gpus):
-    """L2-to-fabric bytes per launch of the roofline kernel from the committed PMC passes (2 x FETCH_SIZE + WRITE_SIZE on
-    gfx950; profiles/README.md).  Counters cannot be read from inside a timed run, so this is the last recorded
-    measurement of the same configuration, or None.  The passes ran `bench.py --steps 1 --warmup 0`: every row but the
-    last (the residual check's product) is a launch of the one factor() call."""
-    if n != 32768 or gpus != 1:
-        return None, None
+    """L2-to-fabric bytes per launch of the roofline kernel from the committed PMC passes of the same configuration
+    (2 x FETCH_SIZE + WRITE_SIZE on gfx950; profiles/README.md).  Counters cannot be read from inside a timed run, so this is
+    a RECORDED figure (`traffic_source` names the files), or None when no pass of this configuration is committed."""
     import csv
+    tag = {(65536, 1): "r2_pmc_{}_bench_n65536.csv", (32768, 1): "r1_d_pmc_{}_bench_step.csv"}.get((n, gpus))
+    if tag is None:
+        return None, None
     tot, launches = 0.0, 0
     try:
-        for tag, name in (("fe", "FETCH_SIZE"), ("wr", "WRITE_SIZE")):
-            rows = [r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", f"r1_d_pmc_{tag}_bench_step.csv"))) if r["Counter_Name"] == name]
-            rows = rows[:-1]
+        for t, name in (("fe", "FETCH_SIZE"), ("wr", "WRITE_SIZE")):
+            rows = [r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", tag.format(t)))) if r["Counter_Name"] == name]
+            rows = rows[:-1]        # the last launch of the pass is the residual check's product, not factor()
             launches = len(rows)
-            # KB; gfx950 tallies a 128-B read request at 64 B (double FETCH_SIZE), WRITE_SIZE reads exactly (MI355X_MICROARCH.md)
             tot += sum(float(r["Counter_Value"]) for r in rows) * 1024 * (2 if name == "FETCH_SIZE" else 1)
     except (OSError, KeyError, ValueError):
         return None, None
     if not launches:
         return None, None
-    return tot / launches, f"profiles/r1_d_pmc_{{fe,wr}}_bench_step.csv: 2 x FETCH_SIZE + WRITE_SIZE, mean of the {launches} launches of one factor()"
+    return tot / launches, f"recorded: profiles/{tag.format('{fe,wr}')}: 2 x FETCH_SIZE + WRITE_SIZE, mean of the {launches} launches of one factor()"
+
+
+def time_cholesky(driver, L, h, n, c, bc, chunks, steps, warmup, distributed, device, bc_policy):
+    prob = driver.Cholinv(n, c=c, complete_inv=0, split=1, bc_mult=bc, layout=0, num_chunks=chunks, serialize=True, bc_policy=bc_policy)
+    prob.generate()
+    for _ in range(warmup):
+        prob.factor()
+    driver.sync()
+    barrier_sync(distributed)
+    L.capi_prof_enable(h, 1)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        prob.factor()
+    driver.sync()
+    barrier_sync(distributed)
+    dt = max_over_ranks(time.perf_counter() - t0, distributed, device)
+    L.capi_prof_enable(h, 0)
+    launches, tot_ms, tot_fl, max_ms = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
+    L.capi_prof_collect(h, 11, C.byref(launches), C.byref(tot_ms), C.byref(tot_fl), C.byref(max_ms))   # 8 + 3: the 128-tile TN kernel, one symbol
+    allv = [C.c_int64(), C.c_double(), C.c_double()]
+    L.capi_prof_collect(h, -1, C.byref(allv[0]), C.byref(allv[1]), C.byref(allv[2]), None)
+    ms = dt / steps * 1e3
+    res = {"ms_per_step": ms, "tflops": n ** 3 / 3.0 / (ms * 1e-3) / 1e12, "residual": prob.residual(), "stats": prob.stats(),
+           "grid": [prob.d, prob.d, prob.c],
+           "kernel": {"launches": launches.value, "ms": tot_ms.value, "flops": tot_fl.value, "max_ms": max_ms.value, "all_tile_ms": allv[1].value}}
+    prob.close()
+    return res
+
+
+def time_cacqr2(driver, m, n, reps, distributed, device):
+    q = driver.Cacqr(m, n, c=1, variant=2)
+    q.generate()
+    q.factor()
+    driver.sync()
+    barrier_sync(distributed)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        q.factor()
+    driver.sync()
+    barrier_sync(distributed)
+    dt = max_over_ranks(time.perf_counter() - t0, distributed, device) / reps
+    out = {"tflops": 4.0 * m * n * n / dt / 1e12, "ms": dt * 1e3, "residual": q.residual(), "orthogonality": q.orthogonality(), "m_loc": q.m_loc}
+    q.close()
+    return out
 
 
 def main():
@@ -88,14 +152,14 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=0, help="override the Cholesky order (diagnostics only)")
-    ap.add_argument("--bc", type=int, default=None, help="bc_mult_dim of cholinv (base-case order = c*d*n / 2^|bc| ... see cholinv.hpp:15-18); "
-                    "default -5 on one GPU (order 1024), -4 on a grid (aggregated order 1024 as well: every recursion node below "
-                    "that costs ~13 latency-bound collectives)")
+    ap.add_argument("--bc", type=int, default=None, help="bc_mult_dim of cholinv (cholinv.hpp:15-18); default: the value that gives an "
+                    "aggregated base-case order of 1024 on this grid (every recursion node below that costs ~13 latency-bound collectives)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-qr", action="store_true")
+    ap.add_argument("--no-config2", action="store_true")
     args = ap.parse_args()
 
-    # a hung collective must end the run with a traceback, not sit on the node until the driver's limit
+    # a hung collective must end the run with a traceback and a non-zero exit, not sit on the node until the driver's limit
     import faulthandler
     faulthandler.dump_traceback_later(int(os.environ.get("CAPITAL_BENCH_WATCHDOG_S", "1500")), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -105,104 +169,94 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (the product has no CPU path)")
+    if args.gpus not in GRID_C:
+        raise SystemExit(f"--gpus must be one of {sorted(GRID_C)} (d*d*c grids of one node)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     from capital_amd import capi, driver
+    rccl = None
     if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)
         driver.init_distributed(local_rank)
+        rccl = driver.world_query()                 # (rank, size) as RCCL reports them for the world communicator
+        assert rccl == (rank, world), f"RCCL world communicator reports rank/size {rccl}, launcher says {(rank, world)}"
     else:
         driver.init(local_rank, 0, 1, None, use_torch_stream=False)
     L = capi.load()
     h = C.c_void_p(driver.handle_ptr())
 
-    if args.gpus not in CHOLESKY_GRID:
-        raise SystemExit(f"--gpus must be one of {sorted(CHOLESKY_GRID)} (d*d*c grids of one node)")
-    if args.bc is None:
-        args.bc = -4 if distributed else -5
-    n, c = CHOLESKY_GRID[args.gpus]
-    if args.n:
-        n = args.n
+    n = args.n or N_CHOLESKY
+    c = GRID_C[args.gpus]
+    d = int(round((args.gpus // c) ** 0.5))
+    bc = args.bc if args.bc is not None else bc_mult_for(n, d, c, BASE_CASE_ORDER)
     # num_chunks > 0 turns on the chunked SUMMA pipeline (collectives on a second HIP stream beside the tile kernel).
     # Off by default until the plain path has been seen to run on a multi-GPU node.
     chunks = int(os.environ.get("CAPITAL_BENCH_CHUNKS", "0")) if distributed else 0
-    prob = driver.Cholinv(n, c=c, complete_inv=0, split=1, bc_mult=args.bc, layout=0, num_chunks=chunks, serialize=True, bc_policy=0 if distributed else 2)
-    prob.generate()
-    for _ in range(args.warmup):
-        prob.factor()
-    driver.sync()
-    barrier_sync(distributed)
-    L.capi_prof_enable(h, 1)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        prob.factor()
-    driver.sync()
-    barrier_sync(distributed)
-    dt = max_over_ranks(time.perf_counter() - t0, distributed, device)
-    L.capi_prof_enable(h, 0)
-    ms_per_step = dt / args.steps * 1e3
-    flops = n ** 3 / 3.0
-    value = flops / (ms_per_step * 1e-3) / 1e12
-
-    # roofline of the dominant kernel: every launch of the 128-tile TN MFMA kernel in the timed region, HIP events on its stream
-    launches, tot_ms, tot_fl, max_ms = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
-    L.capi_prof_collect(h, 11, C.byref(launches), C.byref(tot_ms), C.byref(tot_fl), C.byref(max_ms))   # 8 + 3: the 128-tile TN kernel, one symbol
-    achieved = tot_fl.value / (tot_ms.value * 1e-3) / 1e12 if tot_ms.value > 0 else 0.0
-    allv = [C.c_int64(), C.c_double(), C.c_double()]
-    L.capi_prof_collect(h, -1, C.byref(allv[0]), C.byref(allv[1]), C.byref(allv[2]), None)
-    residual = prob.residual()
-    stats = prob.stats()
+    r = time_cholesky(driver, L, h, n, c, bc, chunks, args.steps, args.warmup, distributed, device, bc_policy=0 if distributed else 2)
+    residual_max = max_over_ranks(r["residual"], distributed, device)
+    k = r["kernel"]
+    achieved = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
     traffic, traffic_src = recorded_traffic(n, args.gpus)
-    prob.close()
 
     out = {
-        "metric": "TFLOP/s (whole node) Cholesky n^3/3, recursive cholinv factor(), inputs resident in HBM",
-        "value": value, "unit": "TFLOP/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "metric": "TFLOP/s (whole node) Cholesky n=65536, algorithmic n^3/3, recursive cholinv factor(), inputs resident in HBM",
+        "value": r["tflops"], "unit": "TFLOP/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"n={n} recursive Cholesky with inverse (cholinv, complete_inv=0, split=1, bc_mult={args.bc}) on a {prob.d}x{prob.d}x{prob.c} GPU grid",
-                   "n": n, "grid": [prob.d, prob.d, prob.c], "base_case_order": stats["bc_dimension"], "residual": residual, "summa_chunks": chunks},
+        "config": {"workload": f"n={n} recursive Cholesky with inverse (cholinv, complete_inv=0, split=1, bc_mult={bc}) on a "
+                               f"{r['grid'][0]}x{r['grid'][1]}x{r['grid'][2]} GPU grid" + (" = BASELINE config 4" if args.gpus == 8 and n == 65536 else ""),
+                   "n": n, "grid": r["grid"], "base_case_order": r["stats"]["bc_dimension"], "residual": residual_max,
+                   "residual_is": "max over ranks of the reference validator (test/cholesky/validate.hpp:7-49)", "summa_chunks": chunks,
+                   "rccl_world": list(rccl) if rccl else None},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "dgemm_tile_kernel<128,true,true> (trailing update + R12 solve, orders >= 4096)",
-                     "launches_per_step": launches.value / max(args.steps, 1),
-                     "avg_launch_ms": tot_ms.value / max(launches.value, 1), "max_launch_ms": max_ms.value,
-                     "avg_flops_per_launch": tot_fl.value / max(launches.value, 1),
-                     "tile_kernel_share_of_step": allv[1].value / (ms_per_step * args.steps) if ms_per_step > 0 else None},
+                     "launches_per_step": k["launches"] / max(args.steps, 1),
+                     "avg_launch_ms": k["ms"] / max(k["launches"], 1), "max_launch_ms": k["max_ms"],
+                     "avg_flops_per_launch": k["flops"] / max(k["launches"], 1),
+                     "tile_kernel_share_of_step": k["all_tile_ms"] / (r["ms_per_step"] * args.steps) if r["ms_per_step"] > 0 else None},
     }
 
-    if not args.no_qr:
-        m_loc, nq = QR_SHAPE_PER_GPU
-        m = m_loc * args.gpus
-        q = driver.Cacqr(m, nq, c=1, variant=2)
-        q.generate()
-        q.factor()
-        driver.sync()
-        barrier_sync(distributed)
-        t0 = time.perf_counter()
-        reps = max(args.steps, 3)
-        for _ in range(reps):
-            q.factor()
-        driver.sync()
-        barrier_sync(distributed)
-        dtq = max_over_ranks(time.perf_counter() - t0, distributed, device) / reps
-        out["cacqr2"] = {"workload": f"CA-CholeskyQR2 m={m} n={nq} (1-D, {args.gpus} GPU)", "tflops": 4.0 * m * nq * nq / dtq / 1e12,
-                         "ms": dtq * 1e3, "algorithmic_GBps_per_gpu": 6 * 8.0 * m_loc * nq / dtq / 1e9,
-                         "residual": q.residual(), "orthogonality": q.orthogonality()}
-        q.close()
+    if args.gpus == 1 and not args.no_config2 and not args.n:
+        n2 = 32768
+        r2 = time_cholesky(driver, L, h, n2, 1, bc_mult_for(n2, 1, 1, BASE_CASE_ORDER), 0, max(args.steps, 3), 1, False, device, bc_policy=2)
+        k2 = r2["kernel"]
+        out["config2"] = {"workload": f"n={n2} recursive Cholesky with inverse on 1 GPU (BASELINE config 2)", "tflops": r2["tflops"],
+                          "ms_per_step": r2["ms_per_step"], "residual": r2["residual"],
+                          "roofline_kernel_tflops": k2["flops"] / (k2["ms"] * 1e-3) / 1e12 if k2["ms"] > 0 else None}
 
-    if rank == 0 and not args.no_cpu and args.gpus == 1:
-        out["cpu_baseline"] = cpu_baseline(10240)      # ~10 s of host work on 16 threads
+    if not args.no_qr:
+        reps = max(args.steps, 3)
+        if args.gpus == 1:
+            m3, n3 = QR_CONFIG3
+            q3 = time_cacqr2(driver, m3, n3, reps, False, device)
+            out["cacqr2"] = {"workload": f"CA-CholeskyQR2 m={m3} n={n3} (1-D, 1 GPU: BASELINE config 3)", "tflops": q3["tflops"], "ms": q3["ms"],
+                             "algorithmic_GBps_per_gpu": 6 * 8.0 * m3 * n3 / (q3["ms"] * 1e-3) / 1e9,
+                             "residual": q3["residual"], "orthogonality": q3["orthogonality"]}
+        m_loc, n5 = QR_CONFIG5_SLICE
+        m5 = m_loc * args.gpus
+        q5 = time_cacqr2(driver, m5, n5, reps, distributed, device)
+        out["cacqr2_config5"] = {"workload": f"CA-CholeskyQR2 m={m5} n={n5} (1-D row blocks, {args.gpus} GPU; per-GPU slice {m_loc} x {n5} of BASELINE config 5"
+                                             + (": m = 2^26 IS config 5)" if args.gpus == 8 else ")"),
+                                 "tflops": q5["tflops"], "ms": q5["ms"], "scaling": "weak (rows per GPU fixed)",
+                                 "roofline_frac_of_fp64_mfma": q5["tflops"] / (FP64_MATRIX_PEAK_TFLOPS * args.gpus),
+                                 "algorithmic_GBps_per_gpu": 6 * 8.0 * m_loc * n5 / (q5["ms"] * 1e-3) / 1e9,
+                                 "residual": max_over_ranks(q5["residual"], distributed, device), "orthogonality": q5["orthogonality"]}
+
     if rank == 0:
+        # register-only MFMA loop, two waves per SIMD, >= 100 ms: what the matrix pipe sustains on THIS device's clocks
         peak = C.c_double()
-        L.capi_mfma_f64_peak(h, 20000, C.byref(peak))
+        L.capi_mfma_f64_peak(h, 250000, C.byref(peak))
         out["mfma_f64_loop_tflops"] = peak.value
-        print(json.dumps(out), flush=True)
-    faulthandler.cancel_dump_traceback_later()
     driver.finalize()
     if distributed:
         dist.destroy_process_group()
+    if rank == 0 and not args.no_cpu and args.gpus == 1:
+        out["cpu_baseline"] = cpu_baseline(16384, 1 << 18, 1024)      # ~25 s of host work on the box's CPU share
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    faulthandler.cancel_dump_traceback_later()
 
 
 if __name__ == "__main__":

@@ -1723,7 +1723,7 @@ int capi_prof_collect(capi_handle_t h, int variant, int64_t* launches, double* t
 int capi_mfma_f64_peak(capi_handle_t h, int iters, double* tflops) {
   CAPI_REQUIRE(h, h && tflops && iters > 0, "args");
   const char* bpc = getenv("CAPI_PEAK_BLOCKS_PER_CU");
-  const int blocks = h->num_cu * (bpc ? atoi(bpc) : 1);  // 4 waves per block: one block per CU = one wave per SIMD
+  const int blocks = h->num_cu * (bpc ? atoi(bpc) : 2);  // 4 waves per block: two blocks per CU = two waves per SIMD (as the tile kernel runs)
   double* out;
   CAPI_HIP_CHECK(h, hipMalloc((void**)&out, sizeof(double) * blocks * 256));
   hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, h->stream, out, 16);  // warm-up

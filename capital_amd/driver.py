@@ -59,6 +59,7 @@ def bind(D):
     D.capital_cacqr_orthogonality.argtypes = [_vp, _dp]
     D.capital_cacqr_get.argtypes = [_vp, _int, _dp]
     D.capital_cacqr_dims.argtypes = [_vp, C.POINTER(_i64), C.POINTER(_i64)]
+    D.capital_cacqr_get_rows.argtypes = [_vp, _int, _i64, _i64, _dp]
     return D
 
 
@@ -115,6 +116,13 @@ def sync():
 
 def handle_ptr():
     return load().capital_drv_handle()
+
+
+def world_query():
+    """(rank, size) of the world communicator as RCCL reports them."""
+    r, s = _int(), _int()
+    _ck(load().capital_drv_world_query(C.byref(r), C.byref(s)), "world_query")
+    return r.value, s.value
 
 
 class Cholinv:
@@ -224,6 +232,16 @@ class Cacqr:
 
     def R(self):
         return self._get(2, (self.n, self.n))
+
+    def gram_of_Q(self):
+        """Q^T Q summed over the ranks (n x n): what the orthogonality validator measures against I."""
+        return self._get(3, (self.n, self.n))
+
+    def rows(self, which, row0, nrows):
+        """Local rows [row0, row0 + nrows) of A (which = 'A') or Q ('Q') -- a bounded window of a panel too large to fetch whole."""
+        out = np.zeros((nrows, self.n), order="F")
+        _ck(self.D.capital_cacqr_get_rows(self.p, {"A": 0, "Q": 1}[which], row0, nrows, out.ctypes.data_as(_dp)), "get_rows")
+        return out
 
     def close(self):
         if self.p:

@@ -82,6 +82,7 @@ struct cacqr_problem {
   virtual double orthogonality() = 0;
   virtual void get(int which, double* host) = 0;
   virtual void dims(int64_t* mloc, int64_t* n) = 0;
+  virtual void get_rows(int which, int64_t row0, int64_t nrows, double* host) = 0;
 };
 
 template <class Alg>
@@ -101,10 +102,28 @@ struct cacqr_impl : cacqr_problem {
   void get(int which, double* host) override {
     if (which == 0) { auto v = A.to_host(); std::memcpy(host, v.data(), sizeof(double) * v.size()); return; }
     if (which == 1) { auto v = Alg::construct_Q(pack, grid).to_host(); std::memcpy(host, v.data(), sizeof(double) * v.size()); return; }
+    if (which == 3) {                                     // Q^T Q (summed over the ranks), n x n
+      matrix<double, int64_t, rect> I(A.num_columns_global(), A.num_columns_global(), 1, 1);
+      qr::validate<Alg>::gram_of_Q(pack, grid, I);
+      auto v = I.to_host();
+      std::memcpy(host, v.data(), sizeof(double) * v.size());
+      return;
+    }
     auto v = Alg::construct_R(pack, grid).to_host();
     std::memcpy(host, v.data(), sizeof(double) * v.size());
   }
   void dims(int64_t* mloc, int64_t* n) override { *mloc = A.num_rows_local(); *n = A.num_columns_local(); }
+  // local rows [row0, row0 + nrows) of A (which = 0) or Q (1), column-major nrows x n: a bounded window of a panel that is
+  // too large to fetch whole (config 5: 64 GiB per GPU)
+  void get_rows(int which, int64_t row0, int64_t nrows, double* host) override {
+    const int64_t m = A.num_rows_local(), n = A.num_columns_local();
+    if (row0 < 0 || nrows < 0 || row0 + nrows > m || (which != 0 && which != 1)) throw std::invalid_argument("cacqr get_rows: window outside the local panel");
+    const double* src = (which == 0 ? A.data() : pack.Q.data()) + row0;
+    double* tmp = capital::dev_alloc(nrows * n);
+    CAPITAL_CHECK(capi_dlacpy(capital::handle(), 0, nrows, n, src, m, tmp, nrows));
+    CAPITAL_CHECK(capi_memcpy_d2h(capital::handle(), host, tmp, sizeof(double) * (size_t)(nrows * n)));
+    capital::dev_free(tmp);
+  }
 };
 
 }  // namespace
@@ -130,6 +149,13 @@ int capital_drv_init(int device, int rank, int size, const void* uid, void* stre
 int capital_drv_finalize(void) { return guarded([] { capital::finalize(); }); }
 int capital_drv_sync(void) { return guarded([] { capital::sync(); }); }
 void* capital_drv_handle(void) { return capital::ctx().handle; }
+// rank and size of the world communicator as RCCL itself reports them (a launcher prints them next to its own)
+int capital_drv_world_query(int* rank, int* size) {
+  return guarded([&] {
+    if (!capital::world()) throw std::runtime_error("no world communicator: call capital_drv_init first");
+    CAPITAL_CHECK(capi_comm_query(capital::world(), rank, size));
+  });
+}
 
 void* capital_cholinv_create(int64_t n, int c, int layout, int num_chunks, int complete_inv, int split, int bc_mult, int serialize_, int bc_policy) {
   cholinv_problem* p = nullptr;
@@ -164,6 +190,7 @@ int capital_cacqr_factor(void* p) { return guarded([&] { ((cacqr_problem*)p)->fa
 int capital_cacqr_residual(void* p, double* out) { return guarded([&] { *out = ((cacqr_problem*)p)->residual(); }); }
 int capital_cacqr_orthogonality(void* p, double* out) { return guarded([&] { *out = ((cacqr_problem*)p)->orthogonality(); }); }
 int capital_cacqr_get(void* p, int which, double* host) { return guarded([&] { ((cacqr_problem*)p)->get(which, host); }); }
+int capital_cacqr_get_rows(void* p, int which, int64_t row0, int64_t nrows, double* host) { return guarded([&] { ((cacqr_problem*)p)->get_rows(which, row0, nrows, host); }); }
 int capital_cacqr_dims(void* p, int64_t* mloc, int64_t* n) { return guarded([&] { ((cacqr_problem*)p)->dims(mloc, n); }); }
 int capital_cacqr_destroy(void* p) { return guarded([&] { capital::sync(); delete (cacqr_problem*)p; }); }
 

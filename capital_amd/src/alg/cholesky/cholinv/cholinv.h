@@ -53,6 +53,9 @@ public:
     DimensionType localDimension = 0, globalDimension = 0, trueLocalDimension = 0, trueGlobalDimension = 0, bcDimension = 0;
     // bookkeeping exposed for tests / benches
     int64_t num_base_cases = 0, num_levels = 0;
+    // LAPACK info of the factorisation (the reference drops it, lapack/interface.hpp:39,54): 0, or the 1-based position,
+    // inside the first diagonal block that failed, of the first non-positive pivot.  factor() throws std::domain_error then.
+    int potrf_info = 0;
     bool zeroed = false;
     // top-level overlap state: the input's right part is copied, and the finished left part packed, on the second stream
     const double* input = nullptr;
@@ -71,6 +74,8 @@ public:
     if (CommInfo.d > 1 && CommInfo.d % CommInfo.c) throw std::invalid_argument("cholinv: c must divide d (or d == 1)");
     const U localDimension = A.num_rows_local(), globalDimension = A.num_rows_global();
     CAPITAL_CHECK(capi_stream_select(capital::handle(), 0));    // (a call that threw mid-way may have left another stream selected)
+    CAPITAL_CHECK(capi_reset_info(capital::handle()));
+    args.potrf_info = 0;
     args.R._register_(A.num_columns_global(), A.num_rows_global(), CommInfo.d, CommInfo.d);
     args.Rinv._register_(A.num_columns_global(), A.num_rows_global(), CommInfo.d, CommInfo.d);
     constexpr bool packed = !std::is_same<typename SP::structure, rect>::value;
@@ -160,6 +165,11 @@ public:
     }
     if (!IP::keep_arena) { capital::sync(); args.work = matmult::arena(); }
     CRITTER_STOP(CI::factor);
+    // one 4-byte read behind the whole launch chain: a non-SPD input must not come back as NaN factors with status OK
+    CAPITAL_CHECK(capi_get_info(capital::handle(), &args.potrf_info));
+    if (args.potrf_info != 0)
+      throw std::domain_error("cholinv::factor: the matrix is not positive definite (non-positive pivot " + std::to_string(args.potrf_info) +
+                              " of a diagonal block); R and Rinv are not valid");
   }
 
   // full local images of the factors (cholinv.hpp:30-46)

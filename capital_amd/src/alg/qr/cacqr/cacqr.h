@@ -45,6 +45,9 @@ public:
     // n x n work blocks (Gram/R of the current sweep, its inverse, R1 of the first sweep, packed transfer image)
     matrix<ScalarType, DimensionType, rect> G, Ginv, R1;
     matrix<ScalarType, DimensionType, uppertri> Gpacked;
+    // LAPACK info of the Gram matrix's factorisation (1-D variant): 0, or the first non-positive pivot (1-based) -- CholeskyQR's
+    // known failure mode is a numerically rank-deficient A^T A (kappa(A) beyond ~1e8).  factor() throws std::domain_error then.
+    int potrf_info = 0;
   };
 
   template <typename MatrixType, typename ArgType, typename CommType>
@@ -110,6 +113,8 @@ protected:
     args.G._register_(n, n, 1, 1);
     args.Ginv._register_(n, n, 1, 1);
     if (SP::packed_gram) args.Gpacked._register_(n, n, 1, 1);
+    CAPITAL_CHECK(capi_reset_info(h));
+    args.potrf_info = 0;
     sweep_1d(A.data(), args.Q.data(), m_loc, n, args, CommInfo);
     if (args.num_iter > 1) {
       args.R1._register_(n, n, 1, 1);
@@ -122,6 +127,11 @@ protected:
     } else {
       finalize_R(args.G, args, n);   // the reference leaves the Gram matrix in R here with Serialize; R is what is documented
     }
+    // one 4-byte read behind the launch chain (the reference drops LAPACK's info, lapack/interface.hpp:39,54)
+    CAPITAL_CHECK(capi_get_info(h, &args.potrf_info));
+    if (args.potrf_info != 0)
+      throw std::domain_error("cacqr::factor: the Gram matrix is not positive definite (pivot " + std::to_string(args.potrf_info) +
+                              "): A is numerically rank deficient for CholeskyQR; Q and R are not valid");
   }
 
   // ---- 3-D variant, c == d (cacqr.hpp:75-116 sweep_3d, :195-215 invoke_3d) ---------------------------------------------

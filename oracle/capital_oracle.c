@@ -38,6 +38,70 @@ int orc_get_threads(void) {
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Host-BLAS backend (bench.py's cpu_baseline leg, and the schedule-level pin of tests/golden).
+ * The reference delegates ALL arithmetic to seven CBLAS / LAPACKE entry points of a host library
+ * (src/blas/interface.hpp:54,74,92; src/lapack/interface.hpp:39,54): orc_host_blas_bind() loads such
+ * a library at run time (MKL's libmkl_rt, OpenBLAS, or the OpenBLAS bundled with numpy / scipy,
+ * whose symbols carry a prefix / suffix and, for the 64_ build, 64-bit integers) and from then on
+ * orc_dgemm / orc_dtrmm / orc_dsyrk / orc_dpotrf / orc_dtrtri forward to it with the constants the
+ * reference passes (column-major, interface.hpp:49-52).  The schedules above them are unchanged, so
+ * "the reference's schedule on the node's own host BLAS" is what gets timed.
+ * ------------------------------------------------------------------------------------------ */
+#include <dlfcn.h>
+#include <stdio.h>
+enum { HB_COL = 102, HB_NOTRANS = 111, HB_TRANS = 112, HB_UPPER = 121, HB_LOWER = 122, HB_NONUNIT = 131, HB_UNIT = 132, HB_LEFT = 141, HB_RIGHT = 142 };
+static struct {
+  int on, ilp64;
+  void* lib;
+  void *gemm, *trmm, *syrk, *potrf, *trtri;
+} g_hb;
+
+int orc_host_blas_bind(const char* path, const char* prefix, const char* suffix, int ilp64) {
+  void* lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+  if (!lib) return -1;
+  const char* names[5] = {"cblas_dgemm", "cblas_dtrmm", "cblas_dsyrk", "LAPACKE_dpotrf", "LAPACKE_dtrtri"};
+  void* f[5];
+  for (int i = 0; i < 5; ++i) {
+    char sym[128];
+    snprintf(sym, sizeof(sym), "%s%s%s", prefix ? prefix : "", names[i], suffix ? suffix : "");
+    f[i] = dlsym(lib, sym);
+    if (!f[i]) { dlclose(lib); return -2 - i; }
+  }
+  g_hb.lib = lib; g_hb.ilp64 = ilp64;
+  g_hb.gemm = f[0]; g_hb.trmm = f[1]; g_hb.syrk = f[2]; g_hb.potrf = f[3]; g_hb.trtri = f[4];
+  g_hb.on = 1;
+  return 0;
+}
+void orc_host_blas_enable(int on) { g_hb.on = on && g_hb.lib; }
+int orc_host_blas_active(void) { return g_hb.on; }
+
+#define HB_CALL(ITYPE)                                                                                              \
+  static void hb_gemm_##ITYPE(int ta, int tb, int64_t m, int64_t n, int64_t k, double al, const double* A, int64_t lda, \
+                              const double* B, int64_t ldb, double be, double* C, int64_t ldc) {                    \
+    ((void (*)(int, int, int, ITYPE, ITYPE, ITYPE, double, const double*, ITYPE, const double*, ITYPE, double, double*, ITYPE))g_hb.gemm)( \
+        HB_COL, ta ? HB_TRANS : HB_NOTRANS, tb ? HB_TRANS : HB_NOTRANS, (ITYPE)m, (ITYPE)n, (ITYPE)k, al, A, (ITYPE)lda, B, (ITYPE)ldb, be, C, (ITYPE)ldc); \
+  }                                                                                                                 \
+  static void hb_trmm_##ITYPE(int side, int uplo, int tr, int diag, int64_t m, int64_t n, double al, const double* T, \
+                              int64_t ldt, double* B, int64_t ldb) {                                                \
+    ((void (*)(int, int, int, int, int, ITYPE, ITYPE, double, const double*, ITYPE, double*, ITYPE))g_hb.trmm)(     \
+        HB_COL, side ? HB_RIGHT : HB_LEFT, uplo ? HB_UPPER : HB_LOWER, tr ? HB_TRANS : HB_NOTRANS, diag ? HB_UNIT : HB_NONUNIT, \
+        (ITYPE)m, (ITYPE)n, al, T, (ITYPE)ldt, B, (ITYPE)ldb);                                                      \
+  }                                                                                                                 \
+  static void hb_syrk_##ITYPE(int uplo, int tr, int64_t n, int64_t k, double al, const double* A, int64_t lda, double be, \
+                              double* C, int64_t ldc) {                                                             \
+    ((void (*)(int, int, int, ITYPE, ITYPE, double, const double*, ITYPE, double, double*, ITYPE))g_hb.syrk)(       \
+        HB_COL, uplo ? HB_UPPER : HB_LOWER, tr ? HB_TRANS : HB_NOTRANS, (ITYPE)n, (ITYPE)k, al, A, (ITYPE)lda, be, C, (ITYPE)ldc); \
+  }                                                                                                                 \
+  static int hb_potrf_##ITYPE(int uplo, int64_t n, double* A, int64_t lda) {                                        \
+    return (int)((ITYPE (*)(int, char, ITYPE, double*, ITYPE))g_hb.potrf)(HB_COL, uplo ? 'U' : 'L', (ITYPE)n, A, (ITYPE)lda); \
+  }                                                                                                                 \
+  static int hb_trtri_##ITYPE(int uplo, int diag, int64_t n, double* A, int64_t lda) {                              \
+    return (int)((ITYPE (*)(int, char, char, ITYPE, double*, ITYPE))g_hb.trtri)(HB_COL, uplo ? 'U' : 'L', diag ? 'U' : 'N', (ITYPE)n, A, (ITYPE)lda); \
+  }
+HB_CALL(int)
+HB_CALL(int64_t)
+
+/* ------------------------------------------------------------------------------------------
  * K1-K3  dgemm  (cblas_dgemm, src/blas/interface.hpp:43-59; call sites summa.hpp:28-30,139-145,
  *                cacqr.hpp:95-96)
  *   C <- alpha*op(A)*op(B) + beta*C,  op(A) m x k, op(B) k x n, column-major.
@@ -107,6 +171,7 @@ void orc_dgemm(int transA, int transB, int64_t m, int64_t n, int64_t k, double a
                const double* A, int64_t lda, const double* B, int64_t ldb,
                double beta, double* C, int64_t ldc) {
   if (m <= 0 || n <= 0) return;
+  if (g_hb.on) { (g_hb.ilp64 ? hb_gemm_int64_t : hb_gemm_int)(transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc); return; }
   /* beta scaling first (BLAS: beta==0 means C is not read) */
   if (beta != 1.0) {
 #pragma omp parallel for schedule(static) if (m * n > 65536)
@@ -176,6 +241,7 @@ static void tri_block_dense(const double* T, int64_t ldt, int uplo, int trans, i
 void orc_dtrmm(int side, int uplo, int trans, int diag, int64_t m, int64_t n, double alpha,
                const double* T, int64_t ldt, double* B, int64_t ldb) {
   if (m <= 0 || n <= 0) return;
+  if (g_hb.on) { (g_hb.ilp64 ? hb_trmm_int64_t : hb_trmm_int)(side, uplo, trans, diag, m, n, alpha, T, ldt, B, ldb); return; }
   int eff_upper = ((uplo == ORC_UPPER) != (trans == ORC_TRANS));
   int64_t nt = side == ORC_LEFT ? m : n;      /* order of T */
   int64_t nb = (nt + TB - 1) / TB;
@@ -225,6 +291,7 @@ void orc_dtrmm(int side, int uplo, int trans, int diag, int64_t m, int64_t n, do
 void orc_dsyrk(int uplo, int trans, int64_t n, int64_t k, double alpha,
                const double* A, int64_t lda, double beta, double* C, int64_t ldc) {
   if (n <= 0) return;
+  if (g_hb.on) { (g_hb.ilp64 ? hb_syrk_int64_t : hb_syrk_int)(uplo, trans, n, k, alpha, A, lda, beta, C, ldc); return; }
   const int64_t SB = 192;
   int64_t nb = (n + SB - 1) / SB;
   double* W = (double*)malloc(sizeof(double) * SB * SB);
@@ -326,6 +393,7 @@ static int potf2_upper(int64_t n, double* A, int64_t lda) {
 
 int orc_dpotrf(int uplo, int64_t n, double* A, int64_t lda) {
   if (n <= 0) return 0;
+  if (g_hb.on) return (g_hb.ilp64 ? hb_potrf_int64_t : hb_potrf_int)(uplo, n, A, lda);
   if (uplo == ORC_LOWER) {
     /* not on the hot path (cholinv asserts dir=='U', cholinv.hpp:9): transpose, factor, transpose back */
     double* W = (double*)malloc(sizeof(double) * n * n);
@@ -371,6 +439,7 @@ static void trti2_upper(int diag, int64_t n, double* A, int64_t lda) {
 
 int orc_dtrtri(int uplo, int diag, int64_t n, double* A, int64_t lda) {
   if (n <= 0) return 0;
+  if (g_hb.on) return (g_hb.ilp64 ? hb_trtri_int64_t : hb_trtri_int)(uplo, diag, n, A, lda);
   if (diag == ORC_NONUNIT)
     for (int64_t i = 0; i < n; ++i) if (A[i + i * lda] == 0.0) return (int)(i + 1);
   if (uplo == ORC_LOWER) {
@@ -711,12 +780,16 @@ static int cacqr_sweep_1d(double* Q, int64_t m, int64_t n, int P, double* G, dou
   memset(G, 0, sizeof(double) * n * n);
   double* Gp = (double*)calloc((size_t)(n * n), sizeof(double));
   int64_t mloc_max = m / P + (m % P ? 1 : 0);
-  double* Qp = (double*)malloc(sizeof(double) * mloc_max * n);
+  double* Qp = P == 1 ? NULL : (double*)malloc(sizeof(double) * mloc_max * n);
   int info = 0;
   for (int p = 0; p < P; ++p) {
     int64_t mloc = (m - p + P - 1) / P;
-    for (int64_t j = 0; j < n; ++j) for (int64_t i = 0; i < mloc; ++i) Qp[i + j * mloc] = Q[(p + i * P) + j * m];
-    orc_dsyrk(ORC_UPPER, ORC_TRANS, n, mloc, 1.0, Qp, mloc, 0.0, Gp, n);
+    if (P == 1) {                                     /* one rank: its block IS the matrix, no gather */
+      orc_dsyrk(ORC_UPPER, ORC_TRANS, n, m, 1.0, Q, m, 0.0, Gp, n);
+    } else {
+      for (int64_t j = 0; j < n; ++j) for (int64_t i = 0; i < mloc; ++i) Qp[i + j * mloc] = Q[(p + i * P) + j * m];
+      orc_dsyrk(ORC_UPPER, ORC_TRANS, n, mloc, 1.0, Qp, mloc, 0.0, Gp, n);
+    }
     for (int64_t j = 0; j < n; ++j) for (int64_t i = 0; i <= j; ++i) G[i + j * n] += Gp[i + j * n];
   }
   info = orc_dpotrf(ORC_UPPER, n, G, n);
@@ -724,6 +797,7 @@ static int cacqr_sweep_1d(double* Q, int64_t m, int64_t n, int P, double* G, dou
   orc_dtrtri(ORC_UPPER, ORC_NONUNIT, n, Ginv, n);
   for (int p = 0; p < P; ++p) {
     int64_t mloc = (m - p + P - 1) / P;
+    if (P == 1) { orc_dtrmm(ORC_RIGHT, ORC_UPPER, ORC_NOTRANS, ORC_NONUNIT, m, n, 1.0, Ginv, n, Q, m); continue; }
     for (int64_t j = 0; j < n; ++j) for (int64_t i = 0; i < mloc; ++i) Qp[i + j * mloc] = Q[(p + i * P) + j * m];
     orc_dtrmm(ORC_RIGHT, ORC_UPPER, ORC_NOTRANS, ORC_NONUNIT, mloc, n, 1.0, Ginv, n, Qp, mloc);
     for (int64_t j = 0; j < n; ++j) for (int64_t i = 0; i < mloc; ++i) Q[(p + i * P) + j * m] = Qp[i + j * mloc];

@@ -1,4 +1,5 @@
-"""BASELINE configs 2 and 3 at FULL size (n = 32768 recursive Cholesky; CA-CholeskyQR2 m = 2^22, n = 256), checked through
+"""BASELINE configs 2 and 3 at FULL size (n = 32768 recursive Cholesky; CA-CholeskyQR2 m = 2^22, n = 256) and the per-GPU slice
+of config 5 (CA-CholeskyQR2 on 2^23 x 1024: what each of the 8 GPUs holds of m = 2^26), checked through
 size-independent properties -- the oracle cannot reach these sizes in test time:
   * the reference's own validators (test/cholesky/validate.hpp, test/qr/validate.hpp) at the tolerances of SURVEY.md 8c
     (Cholesky residual <= 1e-14, CQR2 residual <= 1e-14, orthogonality <= 1e-15);
@@ -65,3 +66,30 @@ def test_cacqr2_config3_full_size_properties(drv):
     rows = np.random.default_rng(7).integers(0, m, size=4096)
     back = Q[torch.from_numpy(rows).cuda()].cpu().numpy() @ R
     assert np.abs(back - A[rows]).max() <= 1e-12 * np.abs(A[rows]).max() * n
+
+
+@pytest.mark.gpu
+def test_cacqr2_config5_slice(drv):
+    """BASELINE config 5 on one of its 8 GPUs: the local 2^23 x 1024 row block (64 GiB; A + Q's two buffers = 192 GiB of the
+    288 GB).  With one rank the Gram all-reduce is the identity, so this is the whole of what a GPU computes in config 5."""
+    m, n = 1 << 23, 1024
+    q = drv.Cacqr(m, n, c=1, variant=2)
+    q.generate()
+    q.factor()
+    drv.sync()
+    res, orth = q.residual(), q.orthogonality()
+    assert res <= 1e-14 and orth <= 1e-15, (res, orth)               # reference validators, SURVEY 8c tolerances
+    R = q.R()
+    assert np.count_nonzero(np.tril(R, -1)) == 0 and (np.diag(R) > 0).all()
+    G = q.gram_of_Q()                                                 # Q^T Q: unit column norms on its diagonal
+    assert np.abs(np.diag(G) - 1.0).max() <= 1e-13
+    assert np.abs(G - np.eye(n)).max() <= 1e-13
+    # A = Q R on row windows spread over the panel (first, last, and random interior ones)
+    rng = np.random.default_rng(11)
+    starts = [0, m - 512] + [int(s) for s in rng.integers(0, m - 512, size=6)]
+    for s0 in starts:
+        Aw, Qw = q.rows("A", s0, 512), q.rows("Q", s0, 512)
+        assert np.abs(Qw @ R - Aw).max() <= 1e-12 * n, s0
+    # the generator's stream position: element (i, j) of the single-rank panel is draw number j m + i + 1 of srand48(0)
+    assert 0.0 <= q.rows("A", m - 1, 1).min() and q.rows("A", m - 1, 1).max() < 1.0
+    q.close()

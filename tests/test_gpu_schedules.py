@@ -115,3 +115,51 @@ def test_cacqr_1d_matches_oracle(drv, oracle, m, n, variant, serialize):
         assert p.orthogonality() <= 1e-15
         assert abs(p.residual() - oracle.qr_residual(A, Qref, Rref)) <= 5e-16
     p.close()
+
+
+def test_cacqr2_width_1024_matches_oracle(drv, oracle):
+    """BASELINE config 5's width (n = 1024) at a height the oracle finishes in seconds: Q, R elementwise against
+    oracle.cacqr_factor_1d (cacqr.hpp:7-29,174-193) on the reference's generator, plus the reference validators."""
+    m, n = 1 << 17, 1024
+    p = drv.Cacqr(m, n, c=1, variant=2, serialize=True)
+    p.generate()
+    A = p.A()
+    np.testing.assert_array_equal(A, oracle.distribute_random(n, m, 0, 0, 1, 1, key=0))
+    p.factor()
+    Q, R = p.Q(), p.R()
+    Qref, Rref, info = oracle.cacqr_factor_1d(A, 1, 2)
+    assert info == 0
+    assert np.abs(R - Rref).max() <= 1e-12 * np.abs(Rref).max()
+    assert np.abs(Q - Qref).max() <= 1e-12 * max(1.0, np.abs(Qref).max())
+    assert np.all(np.tril(R, -1) == 0) and (np.diag(R) > 0).all()
+    assert p.residual() <= 1e-14 and p.orthogonality() <= 1e-15
+    assert abs(p.residual() - oracle.qr_residual(A, Qref, Rref)) <= 5e-16
+    # the row-window accessor and Q^T Q (used by the full-size test) agree with the whole-panel getters
+    np.testing.assert_array_equal(p.rows("Q", 1000, 77), Q[1000:1077])
+    np.testing.assert_array_equal(p.rows("A", m - 5, 5), A[m - 5:])
+    assert np.abs(p.gram_of_Q() - Q.T @ Q).max() <= 1e-13
+    p.close()
+
+
+def test_factor_reports_a_non_spd_input(drv, oracle):
+    """The reference drops LAPACK's info (lapack/interface.hpp:39,54) and returns garbage; here the device-side info word is
+    read once at the end of factor() and a failed pivot raises -- for the recursive Cholesky and for CholeskyQR's Gram matrix."""
+    from capital_amd.driver import DriverError
+    n = 512
+    p = drv.Cholinv(n, bc_mult=-2, serialize=False)
+    A = oracle.distribute_symmetric(n, n, 0, 0, 1, 1)
+    A[300, 300] = -1.0                                    # indefinite: the pivot at global index 300 fails
+    p.set_A(A)
+    with pytest.raises(DriverError, match="not positive definite"):
+        p.factor()
+    p.set_A(oracle.distribute_symmetric(n, n, 0, 0, 1, 1))
+    p.factor()                                            # the handle recovers: the next call starts from a clean info word
+    assert p.residual() <= 1e-14
+    p.close()
+    q = drv.Cacqr(4096, 64, c=1, variant=2)
+    Aq = oracle.distribute_random(64, 4096, 0, 0, 1, 1, key=0)
+    Aq[:, 10] = 0.0                                       # a zero column: A^T A has an exactly zero pivot
+    q.set_A(Aq)
+    with pytest.raises(DriverError, match="not positive definite|rank deficient"):
+        q.factor()
+    q.close()

@@ -205,3 +205,42 @@ def test_cacqr_tunable_grid(oracle, shim_lib, m, n, variant, ci):
         assert np.abs(Rg - Rref).max() <= 1e-12 * np.abs(Rref).max()
         assert np.abs(Qg - Qref).max() <= 1e-12
         assert oracle.qr_orthogonality(Qg) <= 1e-15
+
+
+def test_uid_rendezvous_survives_stale_files(shim_lib, tmp_path):
+    """bench/launch.h's file rendezvous of the RCCL unique id: two launches on the SAME path and run id, the first one
+    leaving all its files behind (a crashed run), plus planted garbage -- every rank of a launch must end with the id
+    rank 0 of THAT launch drew, and a rank without partners must give up with a non-zero exit instead of hanging."""
+    exe = os.path.join(SHIM, "rendezvous_main")
+    path = str(tmp_path / "uid")
+    base = path + ".77"
+
+    def launch(world, keep, timeout_s=20, only=None):
+        procs = []
+        for r in (range(world) if only is None else only):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), CAPITAL_UID_FILE=path, CAPITAL_RUN_ID="77",
+                       CAPITAL_RENDEZVOUS_TIMEOUT_S=str(timeout_s))
+            if keep:
+                env["CAPITAL_KEEP_UID_FILES"] = "1"
+            procs.append(subprocess.Popen([exe], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        return [(p.wait(timeout=60), p.stdout.read().strip(), p.stderr.read()) for p in procs]
+
+    # planted leftovers of an imaginary earlier launch: an id file of the right size, a hello and an ack with old tokens
+    open(base, "wb").write(bytes(128 + 8 * 3))
+    for r in (1, 2):
+        open(f"{base}.hello.{r}", "wb").write(b"\x01" * 8)
+        open(f"{base}.ack.{r}", "wb").write(b"\x01" * 8)
+    first = launch(3, keep=True)
+    assert all(rc == 0 for rc, _, _ in first), first
+    ids1 = {o for _, o, _ in first}
+    assert len(ids1) == 1 and len(next(iter(ids1))) == 256 and next(iter(ids1)) != "00" * 128
+    assert os.path.exists(base)                                   # the "crashed" launch left its files
+    second = launch(3, keep=False)
+    assert all(rc == 0 for rc, _, _ in second), second
+    ids2 = {o for _, o, _ in second}
+    assert len(ids2) == 1 and ids2 != ids1                        # a fresh id, agreed on by all three ranks
+    assert not os.path.exists(base) and not os.path.exists(base + ".hello.1") and not os.path.exists(base + ".ack.2")
+    # a rank whose partners never come up: bounded wait, error exit
+    open(base, "wb").write(bytes(128 + 8 * 2))
+    lone = launch(2, keep=False, timeout_s=2, only=[1])
+    assert lone[0][0] == 3 and "timed out" in lone[0][2]

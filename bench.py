@@ -8,6 +8,7 @@ The matrix is the metric's own, n = 65536, at EVERY N (strong scaling): N = 1 ho
 both factors and the packed copies), N = 8 is BASELINE config 4 (2 x 2 x 2 grid).
 The same JSON line also carries
   * `config2`: n = 32768 on one GPU (BASELINE config 2), N = 1 only;
+  * `cholesky_trsm_mode`: n = 65536 without forming any inverse (not the reference's schedule; an extra), N = 1 only;
   * `cacqr2`: CA-CholeskyQR2 on m = 2^22 x 256 (BASELINE config 3), N = 1 only;
   * `cacqr2_config5`: CA-CholeskyQR2 with the per-GPU slice of BASELINE config 5, 2^23 x 1024 on every GPU (m = 2^23 N:
     weak in m; N = 8 IS config 5, m = 2^26), 4 m n^2 flops;
@@ -102,8 +103,8 @@ def recorded_traffic(n, gpus):
     return tot / launches, f"recorded: profiles/{tag.format('{fe,wr}')}: 2 x FETCH_SIZE + WRITE_SIZE, mean of the {launches} launches of one factor()"
 
 
-def time_cholesky(driver, L, h, n, c, bc, chunks, steps, warmup, distributed, device, bc_policy):
-    prob = driver.Cholinv(n, c=c, complete_inv=0, split=1, bc_mult=bc, layout=0, num_chunks=chunks, serialize=True, bc_policy=bc_policy)
+def time_cholesky(driver, L, h, n, c, bc, chunks, steps, warmup, distributed, device, bc_policy, trsm_mode=False):
+    prob = driver.Cholinv(n, c=c, complete_inv=0, split=1, bc_mult=bc, layout=0, num_chunks=chunks, serialize=True, bc_policy=bc_policy, trsm_mode=trsm_mode)
     prob.generate()
     for _ in range(warmup):
         prob.factor()
@@ -225,6 +226,13 @@ def main():
         out["config2"] = {"workload": f"n={n2} recursive Cholesky with inverse on 1 GPU (BASELINE config 2)", "tflops": r2["tflops"],
                           "ms_per_step": r2["ms_per_step"], "residual": r2["residual"],
                           "roofline_kernel_tflops": k2["flops"] / (k2["ms"] * 1e-3) / 1e12 if k2["ms"] > 0 else None}
+
+    if args.gpus == 1 and not args.no_config2 and not args.n:
+        # NOT the headline: the same matrix factored without forming any inverse (info::solve_with_trsm: potrf + block TRSM + SYRK,
+        # what BASELINE north_star names; executes n^3/3 instead of the reference schedule's 5 n^3/12).  Same R, no R^-1.
+        rt = time_cholesky(driver, L, h, n, 1, bc, 0, 2, 1, False, device, bc_policy=2, trsm_mode=True)
+        out["cholesky_trsm_mode"] = {"workload": f"n={n} Cholesky, TRSM mode (R only, no inverse formed), 1 GPU", "tflops": rt["tflops"],
+                                     "ms_per_step": rt["ms_per_step"], "residual": rt["residual"]}
 
     if not args.no_qr:
         reps = max(args.steps, 3)

@@ -29,9 +29,10 @@ inline int env_int(const char* name, int dflt) {
 // exception (non-zero exit), and rank 0 removes the files once the communicator is up:
 //   rank r > 0 : draws a random token, publishes  <path>.<run>.hello.<r>  = token   (re-publishes it if it disappears)
 //   rank 0     : consumes the hello files; once it holds a token per rank it publishes  <path>.<run>  = id + tokens
-//   rank r > 0 : accepts the id file only if ITS token is in it, then publishes  <path>.<run>.ack.<r> = token
-//   rank 0     : proceeds when every ack carries the token it published for that rank; a newer hello (it had consumed a
-//                stale one) replaces the token and the id file is rewritten.
+//   rank r > 0 : accepts the id file only if ITS token is in it, then publishes  <path>.<run>.ack.<r> = token + head of the id
+//   rank 0     : proceeds when every ack carries the token it published for that rank AND the head of THIS launch's id (a
+//                hello/ack pair left by one earlier launch shares a token, but cannot know the new id); a newer hello (it
+//                had consumed a stale one) replaces the token and the id file is rewritten.
 // <run> = CAPITAL_RUN_ID, else TORCHELASTIC_RUN_ID, else MASTER_PORT, else "0" -- a launcher-provided nonce keeps
 // concurrent launches that share a path apart; correctness against stale files does not depend on it.
 namespace detail {
@@ -97,9 +98,9 @@ inline void rendezvous_uid(const std::string& path, int rank, int size, unsigned
       }
       bool done = all && !dirty;
       for (int r = 1; r < size && done; ++r) {
-        if (!acked[r] && detail::read_file(ack(r), buf) && buf.size() == 8) {
-          uint64_t t; memcpy(&t, buf.data(), 8);
-          acked[r] = (t == tok[r]);
+        if (!acked[r] && detail::read_file(ack(r), buf) && buf.size() == 16) {
+          // token AND the head of the id it accepted: an ack left by an earlier launch carries that launch's id
+          acked[r] = memcmp(buf.data(), &tok[r], 8) == 0 && memcmp(buf.data() + 8, uid, 8) == 0;
         }
         done = acked[r];
       }
@@ -121,7 +122,10 @@ inline void rendezvous_uid(const std::string& path, int rank, int size, unsigned
       if (expired()) throw std::runtime_error("rendezvous: rank " + std::to_string(rank) + " timed out waiting for this launch's id at " + base);
       nap();
     }
-    detail::write_atomic(ack(rank), &mine, 8);
+    unsigned char a16[16];
+    memcpy(a16, &mine, 8);
+    memcpy(a16 + 8, uid, 8);
+    detail::write_atomic(ack(rank), a16, 16);
   }
 }
 

@@ -47,6 +47,13 @@ int main(int argc, char** argv) {
         std::cout << "total time - " << total_time << "   (" << 2.0 * (double)M * (double)N * (double)K / total_time / 1e12
                   << " TFLOP/s, " << size << " GPU)" << std::endl;
     }
+    // CAPITAL_BENCH_DUMP=<path>: this rank's local block of C (column-major doubles) for an elementwise check against A B
+    if (const char* dump = getenv("CAPITAL_BENCH_DUMP")) {
+      auto host = matC.to_host();
+      FILE* f = fopen((std::string(dump) + "." + std::to_string(rank)).c_str(), "wb");
+      if (!f || fwrite(host.data(), sizeof(double), host.size(), f) != host.size()) { std::cerr << "cannot write " << dump << "\n"; return 1; }
+      fclose(f);
+    }
   }
   capital::finalize();
   return 0;

@@ -87,7 +87,6 @@ struct GemmArgs {
   int ts;             // tile size chosen by the launcher
   int no_skip;        // diagnostics: never skip zero sub-tiles
   int share_ab;       // A and B are the same matrix in the same orientation (syrk): diagonal tiles stage ONE panel
-  int tall_order;     // right-side TRMM on a tall operand: tiles are dealt as a plain product's (bands of 8 row tiles x all column tiles per XCD)
 };
 
 // ---- global -> registers: this thread's 4 x 16 bytes of a 128 x 16 operand panel -----------------
@@ -295,7 +294,7 @@ __global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel
   const int pid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
   int z = pid / p.ntiles;
   int ti, tj;
-  if (p.tri_side >= 0 && p.splitk == 1 && !p.tall_order) { z = 0; trmm_tile_of(p, bid, ti, tj); }
+  if (p.tri_side >= 0 && p.splitk == 1) { z = 0; trmm_tile_of(p, bid, ti, tj); }
   else tile_of(p, pid - z * p.ntiles, ti, tj);
   if (p.tail_base > 0) {                      // quarters outside the matrix or wholly in the unwanted triangle (uniform per workgroup)
     if (ti >= p.tiles_m || tj >= p.tiles_n) return;
@@ -1420,13 +1419,8 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
       if (t < best) { best = t; best_ts = ts; best_s = sk; }
     }
   }
-  // Right-side TRMM on a tall operand wider than the full-width kernel above (CholeskyQR2's Q = A R^-1 at n = 512..1024;
-  // config 5 is 2^23 x 1024 per GPU).  CAPI_TALL_MODE=3 deals its tiles like a plain product's instead of longest-first.
-  static const int tall_mode = getenv("CAPI_TALL_MODE") ? atoi(getenv("CAPI_TALL_MODE")) : 0;
-  const bool tall_trmm = tall_mode == 3 && !force_ts && p.tri_side == CAPI_RIGHT && !ak && p.batch <= 1 && cdiv(p.M, 128) >= 64 * cdiv(p.N, 128) && p.N >= 256;
-  if (tall_trmm) { best_ts = 128; best_s = 1; }
   static const bool dbg = getenv("CAPI_DEBUG_GEMM") != nullptr;
-  if (dbg) fprintf(stderr, "[capi gemm] M=%d N=%d K=%d uplo=%d tri=%d -> ts=%d splitk=%d est=%.1f us%s\n", p.M, p.N, p.K, p.out_uplo, p.tri_side, best_ts, best_s, best, tall_trmm ? " (tall order)" : "");
+  if (dbg) fprintf(stderr, "[capi gemm] M=%d N=%d K=%d uplo=%d tri=%d -> ts=%d splitk=%d est=%.1f us\n", p.M, p.N, p.K, p.out_uplo, p.tri_side, best_ts, best_s, best);
   // latency-bound sizes go to the burst-load 32-tile kernel: one workgroup per CU (139 KB of LDS), per 256-deep chunk
   // ~2 us of exposed load latency + 64 MFMAs per wave
   {
@@ -1444,7 +1438,6 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
       use_small = nt32 <= thin_rounds * slots;
     }
     if (force_small) use_small = atoi(force_small) != 0 && p.M <= 4096 && p.N <= 4096;
-    if (tall_trmm) use_small = false;
     if (dbg) fprintf(stderr, "[capi gemm]   small-kernel estimate %.1f us -> %s\n", t_small, use_small ? "small" : "tile");
     if (use_small) {
       const int kcap = p.K >= SKC ? SKC : (int)(cdiv(p.K, SQK) * SQK);      // staged depth: LDS holds 2 x kcap x SLD doubles
@@ -1506,8 +1499,7 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
   p.ntiles -= tail128;
   gemm_kernel_t k = p.ts == 128 ? pick_kernel<128>(ak, bkc) : pick_kernel<64>(ak, bkc);
   const size_t lds_bytes = sizeof(double) * 2 * (p.ts == 128 ? tile_cfg<128>::STAGE_LDS : tile_cfg<64>::STAGE_LDS);
-  p.tall_order = tall_trmm ? 1 : 0;
-  const int64_t nblk = tall_trmm ? (int64_t)p.tiles_m * p.tiles_n : (int64_t)p.ntiles * p.splitk;
+  const int64_t nblk = (int64_t)p.ntiles * p.splitk;
   CAPI_REQUIRE(h, nblk < (int64_t)1 << 31, "too many tiles");
   capi_handle_s::prof_rec* rec = nullptr;
   if (h->prof_on) {

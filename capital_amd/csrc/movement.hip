@@ -112,6 +112,28 @@ __global__ void block_cyclic_kernel(int to_cyclic, double* __restrict__ blocked,
   }
 }
 
+// Packed-triangle form (util.hpp:57-102, 167-201): the d*d pieces are the ranks' local blocks of an UPPER triangular aggregate,
+// each stored packed upper (local column i holds rows 0..i at offset i(i+1)/2: structure.h:39) -- rl(rl+1)/2 doubles per piece
+// instead of rl^2, which is what travels in the base-case gather / scatter with the Serialize policy (policy.h:176,322-377).
+// Local (column i, row k <= i) of piece (x, y) is global (i d + x, k d + y); on the local diagonal (k == i) only pieces with
+// y <= x lie in the aggregate's upper triangle.  to_cyclic: the aggregate's strictly lower part is zeroed, as in the rect form.
+// to_blocked: packed entries that lie BELOW the aggregate's diagonal (k == i, y > x) are written as zeros -- the reference's
+// cyclic_to_block_triangle leaves them untouched (stale), one reason its Serialize x NoReplication combination returns
+// wrong factors.
+__global__ void block_cyclic_tri_kernel(int to_cyclic, double* __restrict__ blocked, double* __restrict__ cyclic, int64_t rl, int64_t d) {
+  const int64_t grow = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t rg = rl * d, psz = rl * (rl + 1) / 2;
+  if (grow >= rg) return;
+  for (int64_t gcol = blockIdx.y; gcol < rg; gcol += gridDim.y) {
+    const int64_t i = gcol / d, x = gcol % d, k = grow / d, y = grow % d;
+    if (k > i) { if (to_cyclic) cyclic[gcol * rg + grow] = 0.0; continue; }      // below every piece's packed triangle
+    const int64_t b = (y * d + x) * psz + i * (i + 1) / 2 + k;
+    const bool below = grow > gcol;                                            // k == i && y > x
+    if (to_cyclic) cyclic[gcol * rg + grow] = below ? 0.0 : blocked[b];
+    else blocked[b] = below ? 0.0 : cyclic[gcol * rg + grow];
+  }
+}
+
 // ---- POSIX drand48 in closed form (the reference calls srand48/drand48: structure.hpp:68-129) ----
 constexpr uint64_t LCG_A = 0x5DEECE66DULL, LCG_C = 0xBULL, LCG_MASK = (1ULL << 48) - 1;
 
@@ -303,6 +325,19 @@ int capi_block_to_cyclic(capi_handle_t h, const double* blocked, double* cyclic,
 int capi_cyclic_to_block(capi_handle_t h, double* blocked, const double* cyclic, int64_t rl, int64_t cl, int64_t d) {
   CAPI_REQUIRE(h, h && blocked && cyclic && rl > 0 && cl > 0 && d > 0, "args");
   hipLaunchKernelGGL(block_cyclic_kernel, grid2(rl * d, cl * d), dim3(256), 0, h->stream, 0, blocked, (double*)cyclic, rl, cl, d);
+  CAPI_HIP_CHECK(h, hipGetLastError());
+  return CAPI_OK;
+}
+
+int capi_block_to_cyclic_tri(capi_handle_t h, const double* blocked, double* cyclic, int64_t rl, int64_t d) {
+  CAPI_REQUIRE(h, h && blocked && cyclic && rl > 0 && d > 0, "args");
+  hipLaunchKernelGGL(block_cyclic_tri_kernel, grid2(rl * d, rl * d), dim3(256), 0, h->stream, 1, (double*)blocked, cyclic, rl, d);
+  CAPI_HIP_CHECK(h, hipGetLastError());
+  return CAPI_OK;
+}
+int capi_cyclic_to_block_tri(capi_handle_t h, double* blocked, const double* cyclic, int64_t rl, int64_t d) {
+  CAPI_REQUIRE(h, h && blocked && cyclic && rl > 0 && d > 0, "args");
+  hipLaunchKernelGGL(block_cyclic_tri_kernel, grid2(rl * d, rl * d), dim3(256), 0, h->stream, 0, blocked, (double*)cyclic, rl, d);
   CAPI_HIP_CHECK(h, hipGetLastError());
   return CAPI_OK;
 }

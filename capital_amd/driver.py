@@ -52,6 +52,7 @@ def bind(D):
     D.capital_cholinv_get.argtypes = [_vp, _int, _dp]
     D.capital_cholinv_dims.argtypes = [_vp, C.POINTER(_i64)] + [C.POINTER(_int)] * 5
     D.capital_cholinv_stats.argtypes = [_vp] + [C.POINTER(_i64)] * 3
+    D.capital_cholinv_set_trsm_mode.argtypes = [_vp, _int]
     D.capital_cacqr_create.argtypes = [_i64, _i64] + [_int] * 8
     D.capital_cacqr_create.restype = _vp
     D.capital_cacqr_set_A.argtypes = [_vp, _dp]
@@ -88,7 +89,7 @@ def init_distributed(device):
     import torch.distributed as dist
     rank, size = dist.get_rank(), dist.get_world_size()
     uid = None
-    if size > 1:
+    if size > 1 or os.environ.get("CAPI_RCCL_FORCE"):      # (CAPI_RCCL_FORCE: even a 1-rank communicator goes through RCCL)
         L = capi.load()
         torch_rccl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
         if os.path.exists(torch_rccl):
@@ -129,11 +130,13 @@ class Cholinv:
     """cholesky::cholinv<SP,SaveIntermediates,BP>::factor on this process's block of an n x n SPD matrix.
     Arguments in the order of the reference bench (bench/cholesky/cholinv.cpp:15-22)."""
 
-    def __init__(self, n, c=1, complete_inv=0, split=1, bc_mult=0, layout=0, num_chunks=0, serialize=True, bc_policy=2):
+    def __init__(self, n, c=1, complete_inv=0, split=1, bc_mult=0, layout=0, num_chunks=0, serialize=True, bc_policy=2, trsm_mode=False):
         self.D = load()
         self.p = self.D.capital_cholinv_create(n, c, layout, num_chunks, int(complete_inv), split, bc_mult, int(serialize), bc_policy)
         if not self.p:
             raise DriverError("capital_cholinv_create: " + self.D.capital_drv_last_error().decode())
+        if trsm_mode:      # info::solve_with_trsm: potrf + block TRSM + SYRK, no inverse formed (not the reference's schedule)
+            _ck(self.D.capital_cholinv_set_trsm_mode(self.p, 1), "set_trsm_mode")
         nloc, x, y, z, d, cc = _i64(), _int(), _int(), _int(), _int(), _int()
         _ck(self.D.capital_cholinv_dims(self.p, C.byref(nloc), C.byref(x), C.byref(y), C.byref(z), C.byref(d), C.byref(cc)), "dims")
         self.n, self.n_loc, self.x, self.y, self.z, self.d, self.c = n, nloc.value, x.value, y.value, z.value, d.value, cc.value

@@ -36,6 +36,7 @@ struct cholinv_problem {
   virtual void get(int which, double* host) = 0;
   virtual void dims(int64_t* nloc, int* x, int* y, int* z, int* d, int* c) = 0;
   virtual void stats(int64_t* bc, int64_t* levels, int64_t* bcdim) = 0;
+  virtual void set_trsm_mode(bool on) = 0;
 };
 
 template <class Alg>
@@ -59,6 +60,7 @@ struct cholinv_impl : cholinv_problem {
     *nloc = A.num_rows_local(); *x = (int)grid.x; *y = (int)grid.y; *z = (int)grid.z; *d = (int)grid.d; *c = (int)grid.c;
   }
   void stats(int64_t* bc, int64_t* levels, int64_t* bcdim) override { *bc = pack.num_base_cases; *levels = pack.num_levels; *bcdim = pack.bcDimension; }
+  void set_trsm_mode(bool on) override { pack.solve_with_trsm = on; }
 };
 
 template <class SP>
@@ -173,6 +175,8 @@ int capital_cholinv_residual(void* p, double* out) { return guarded([&] { *out =
 int capital_cholinv_get(void* p, int which, double* host) { return guarded([&] { ((cholinv_problem*)p)->get(which, host); }); }
 int capital_cholinv_dims(void* p, int64_t* nloc, int* x, int* y, int* z, int* d, int* c) { return guarded([&] { ((cholinv_problem*)p)->dims(nloc, x, y, z, d, c); }); }
 int capital_cholinv_stats(void* p, int64_t* bc, int64_t* levels, int64_t* bcdim) { return guarded([&] { ((cholinv_problem*)p)->stats(bc, levels, bcdim); }); }
+// TRSM mode (info::solve_with_trsm): potrf + block TRSM + SYRK recursion, no inverse formed; one GPU per matrix
+int capital_cholinv_set_trsm_mode(void* p, int on) { return guarded([&] { ((cholinv_problem*)p)->set_trsm_mode(on != 0); }); }
 int capital_cholinv_destroy(void* p) { return guarded([&] { capital::sync(); delete (cholinv_problem*)p; }); }
 
 void* capital_cacqr_create(int64_t m, int64_t n, int c, int variant, int layout, int num_chunks, int complete_inv, int split, int bc_mult, int serialize_) {

@@ -53,6 +53,11 @@ public:
     DimensionType localDimension = 0, globalDimension = 0, trueLocalDimension = 0, trueGlobalDimension = 0, bcDimension = 0;
     // bookkeeping exposed for tests / benches
     int64_t num_base_cases = 0, num_levels = 0;
+    // TRSM mode (not in the reference, which has no TRSM anywhere; BASELINE north_star names the kernel): factor() runs the
+    // textbook right-looking recursion -- potrf on the diagonal block, R12 = R11^-T A12 by a block TRSM, trailing SYRK -- and
+    // forms NO inverse: n^3/3 executed flops instead of 5 n^3/12.  R is the same factor; Rinv is not formed (construct_Rinv
+    // throws).  One GPU per matrix (d == 1).  Default off: the reference-exact schedule.
+    bool solve_with_trsm = false;
     // LAPACK info of the factorisation (the reference drops it, lapack/interface.hpp:39,54): 0, or the 1-based position,
     // inside the first diagonal block that failed, of the first non-positive pivot.  factor() throws std::domain_error then.
     int potrf_info = 0;
@@ -72,6 +77,7 @@ public:
     static_assert(std::is_same<typename MatrixType::StructureType, rect>::value, "cholinv::factor takes a rect-structured input block");
     if (!(args.split > 0) || args.dir != 'U') throw std::invalid_argument("cholinv: split > 0 and dir == 'U' required (cholinv.hpp:9)");
     if (CommInfo.d > 1 && CommInfo.d % CommInfo.c) throw std::invalid_argument("cholinv: c must divide d (or d == 1)");
+    if (args.solve_with_trsm) { factor_trsm(A, args, CommInfo); CRITTER_STOP(CI::factor); return; }
     const U localDimension = A.num_rows_local(), globalDimension = A.num_rows_global();
     CAPITAL_CHECK(capi_stream_select(capital::handle(), 0));    // (a call that threw mid-way may have left another stream selected)
     CAPITAL_CHECK(capi_reset_info(capital::handle()));
@@ -172,6 +178,66 @@ public:
                               " of a diagonal block); R and Rinv are not valid");
   }
 
+  // ---- TRSM mode -----------------------------------------------------------------------------------------------------------
+  // R = chol(A) with the same split rule and base-case size as the reference recursion (cholinv.hpp:15-18,93,107), but
+  //   2'. R12 = R11^-T A12 by capi_dtrsm (block TRSM: products on the MFMA tile kernel, 256-blocks inverted on the fly)
+  //   3.  A22 <- A22 - R12^T R12 by capi_dsyrk (upper triangle only)
+  // and no step 5; the base case is capi_dpotrf alone.  Nothing of R^-1 is formed.
+  template <typename MatrixType, typename ArgType, typename CommType>
+  static void factor_trsm(const MatrixType& A, ArgType& args, CommType&& CommInfo) {
+    using U = typename ArgType::DimensionType;
+    if (CommInfo.d != 1) throw std::invalid_argument("cholinv: the TRSM mode keeps the matrix on one GPU (d == 1); grids use the reference schedule");
+    capi_handle_t h = capital::handle();
+    const U ld = A.num_rows_local();
+    CAPITAL_CHECK(capi_stream_select(h, 0));
+    CAPITAL_CHECK(capi_reset_info(h));
+    args.potrf_info = 0;
+    args.R._register_(A.num_columns_global(), A.num_rows_global(), CommInfo.d, CommInfo.d);
+    constexpr bool packed = !std::is_same<typename SP::structure, rect>::value;
+    if (packed) args.Rfull._register_(A.num_columns_global(), A.num_rows_global(), CommInfo.d, CommInfo.d);
+    double* R = packed ? args.Rfull.data() : (double*)args.R.data();
+    if (!args.zeroed) { capital::dev_zero(R, ld * ld); args.zeroed = true; }
+    CAPITAL_CHECK(capi_dlacpy(h, 1, ld, ld, A.data(), ld, R, ld));                                   // cholinv.hpp:13
+    U bcDimLocal = (U)(CommInfo.c * CommInfo.d), bcMult = args.bc_mult_dim;                           // cholinv.hpp:15-18
+    if (bcMult < 0) { bcMult = -bcMult; for (U i = 0; i < bcMult; ++i) bcDimLocal *= 2; } else { for (U i = 0; i < bcMult; ++i) bcDimLocal /= 2; }
+    bcDimLocal = ld / std::min<U>(ld, std::max<U>(1, bcDimLocal));
+    args.localDimension = args.trueLocalDimension = ld;
+    args.globalDimension = args.trueGlobalDimension = A.num_rows_global();
+    args.bcDimension = (U)CommInfo.d * bcDimLocal;
+    args.num_base_cases = args.num_levels = 0;
+    potrf_rec(args, R, ld, (U)0, ld);
+    if (packed) serialize<uppertri, uppertri>::invoke(args.Rfull, args.R, 0, ld, 0, ld, 0, ld, 0, ld);
+    CAPITAL_CHECK(capi_get_info(h, &args.potrf_info));
+    if (args.potrf_info != 0)
+      throw std::domain_error("cholinv::factor (TRSM mode): the matrix is not positive definite (non-positive pivot " + std::to_string(args.potrf_info) + " of a diagonal block)");
+  }
+
+  template <typename ArgType, typename U>
+  static void potrf_rec(ArgType& args, double* R, U ld, U start, U dim) {
+    capi_handle_t h = capital::handle();
+    const U split1 = dim >> args.split;
+    double* R11 = R + start + start * ld;
+    if (dim <= args.bcDimension || split1 < args.split) {                                            // cholinv.hpp:93
+      CRITTER_START(CI::factor_diag);
+      CAPITAL_CHECK(capi_dpotrf(h, CAPI_UPPER, dim, R11, ld));
+      CRITTER_STOP(CI::factor_diag);
+      ++args.num_base_cases;
+      return;
+    }
+    ++args.num_levels;
+    const U split2 = dim - split1;
+    double* R12 = R + start + (start + split1) * ld;
+    double* R22 = R + (start + split1) + (start + split1) * ld;
+    potrf_rec(args, R, ld, start, split1);
+    CRITTER_START(CI::trsm);
+    CAPITAL_CHECK(capi_dtrsm(h, CAPI_LEFT, CAPI_UPPER, CAPI_TRANS, CAPI_NONUNIT, split1, split2, 1.0, R11, ld, R12, ld));
+    CRITTER_STOP(CI::trsm);
+    CRITTER_START(CI::tmu);
+    CAPITAL_CHECK(capi_dsyrk(h, CAPI_UPPER, CAPI_TRANS, split2, split1, -1.0, R12, ld, 1.0, R22, ld));
+    CRITTER_STOP(CI::tmu);
+    potrf_rec(args, R, ld, start + split1, split2);
+  }
+
   // full local images of the factors (cholinv.hpp:30-46)
   template <typename ArgType, typename CommType>
   static matrix<typename ArgType::ScalarType, typename ArgType::DimensionType, rect> construct_R(ArgType& args, CommType&& CommInfo) {
@@ -179,6 +245,7 @@ public:
   }
   template <typename ArgType, typename CommType>
   static matrix<typename ArgType::ScalarType, typename ArgType::DimensionType, rect> construct_Rinv(ArgType& args, CommType&& CommInfo) {
+    if (args.solve_with_trsm) throw std::logic_error("cholinv: the TRSM mode forms no inverse (info::solve_with_trsm)");
     return construct(args.Rinv, CommInfo);
   }
 
@@ -186,6 +253,7 @@ private:
   // event slots of the top-level overlap (matmult::summa's pipe uses slots below 1000)
   static constexpr int EV_INPUT_HEAD = 1020, EV_INPUT_REST = 1021, EV_TOP_R12 = 1022, EV_EARLY_PACK = 1023, EV_INPUT_MID = 1019;
   // lookahead (single GPU): slot + depth; the bulk streams are stream indices LA_STREAM0 + depth
+  static constexpr int EV_BC_POTRF = 1008, EV_BC_SCATTER = 1009;      // NoReplicationOverlap: scatter of R beside trtri
   static constexpr int EV_LA_LEAD = 1010, EV_LA_REST = 1014, LA_STREAM0 = 2, LA_MAX_DEPTH = 2;
   // smallest trailing block whose update is split (CAPITAL_LOOKAHEAD_MIN, default 2048; CAPITAL_NO_LOOKAHEAD turns it off);
   // read per call so that tests can exercise the path at small orders
@@ -363,35 +431,109 @@ private:
       CAPITAL_CHECK(capi_dpotrf_trtri(h, localDim, Rb, ld, Ib, ld));
       return;
     }
-    const int64_t d = (int64_t)t.d, agg = (int64_t)localDim * d, piece = (int64_t)localDim * localDim;
+    const int64_t d = (int64_t)t.d, L = (int64_t)localDim, agg = L * d;
     // `span`: the aggregate minus the global padding when this is the last block (policy.h:196)
     const int64_t span = ((start + localDim) != args.trueLocalDimension) ? agg : agg - (args.trueLocalDimension * d - args.trueGlobalDimension);
+    // With Serialize the pieces travel PACKED, L (L + 1) / 2 doubles instead of L^2 (policy.h:176: the messages are
+    // base_case_table[...].num_elems() of an uppertri block) and are re-indexed by the triangle forms (util.hpp:57-102,167-201).
+    constexpr bool packed_msg = !std::is_same<typename SP::structure, rect>::value;
+    const int64_t piece = packed_msg ? L * (L + 1) / 2 : L * L;
+    auto pack_piece = [&](const double* blk, double* dst) {          // local block (ld) -> message piece
+      if (packed_msg) CAPITAL_CHECK(capi_serialize_shape(h, CAPI_UPPERTRI, CAPI_RECT, CAPI_UPPERTRI, blk, ld, ld, dst, L, L, 0, L, 0, L, 0, L, 0, L));
+      else CAPITAL_CHECK(capi_dlacpy(h, 0, L, L, blk, ld, dst, L));
+    };
+    auto unpack_piece = [&](const double* src, double* blk) {        // message piece -> local block (ld); strictly-lower part stays zero
+      if (packed_msg) CAPITAL_CHECK(capi_serialize_shape(h, CAPI_UPPERTRI, CAPI_UPPERTRI, CAPI_RECT, src, L, L, blk, ld, ld, 0, L, 0, L, 0, L, 0, L));
+      else CAPITAL_CHECK(capi_dlacpy(h, 0, L, L, src, L, blk, ld));
+    };
+    auto to_cyclic = [&](const double* blocked, double* cyc) {
+      if (packed_msg) CAPITAL_CHECK(capi_block_to_cyclic_tri(h, blocked, cyc, L, d));
+      else util::block_to_cyclic_rect(blocked, cyc, L, L, d);
+    };
+    auto to_blocked = [&](double* blocked, const double* cyc) {
+      if (packed_msg) CAPITAL_CHECK(capi_cyclic_to_block_tri(h, blocked, cyc, L, d));
+      else util::cyclic_to_block_rect(blocked, cyc, L, L, d);
+    };
     matmult::arena& ws = args.work;
     const int64_t mark = ws.top;
-    double* mine = ws.take(piece);
-    double* blocked = ws.take(piece * d * d);
-    double* cyc = ws.take(agg * agg);
-    double* cyci = ws.take(agg * agg);
+    double* mine = ws.take(piece);        // this rank's piece of A (in), then of R (out)
+    double* minei = ws.take(piece);       // this rank's piece of R^-1 (out)
+    const int64_t me = (int64_t)t.x + d * (int64_t)t.y;            // rank inside `slice` (topology.h:85,93-94)
     const bool worker = BP::every_layer || t.z == 0;
-    if (worker) {
-      CAPITAL_CHECK(capi_dlacpy(h, 0, localDim, localDim, Rb, ld, mine, localDim));
-      // C5 (Allgather over slice); the gather-to-root strategies (C6) are served by the same collective: on xGMI an
-      // all-gather of bc_loc^2 doubles costs the same single step as a gather and saves the scatter on the way back
-      CAPITAL_CHECK(capi_allgather(t.slice, mine, blocked, piece));
-      util::block_to_cyclic_rect(blocked, cyc, localDim, localDim, d);
-      capital::dev_zero(cyci, agg * agg);
-      CAPITAL_CHECK(capi_dpotrf_trtri(h, span, cyc, agg, cyci, agg));
+    if (BP::gather_all) {
+      // ReplicateCommComp (policy.h:160-224) / ReplicateComp (:226-305): Allgather over the slice, every rank of the (or of
+      // layer 0's) slice re-indexes, factors and inverts the aggregate and keeps its own piece
+      double* blocked = ws.take(piece * d * d);
+      double* cyc = ws.take(agg * agg);
+      double* cyci = ws.take(agg * agg);
+      if (worker) {
+        pack_piece(Rb, mine);
+        CAPITAL_CHECK(capi_allgather(t.slice, mine, blocked, piece));                      // C5, policy.h:176,240
+        to_cyclic(blocked, cyc);
+        capital::dev_zero(cyci, agg * agg);
+        CAPITAL_CHECK(capi_dpotrf_trtri(h, span, cyc, agg, cyci, agg));                    // policy.h:199-201
+      }
+      if (!BP::every_layer) {                                                              // C7, policy.h:288-289: the aggregates travel
+        CAPITAL_CHECK(capi_bcast(t.depth, cyc, agg * agg, 0));
+        CAPITAL_CHECK(capi_bcast(t.depth, cyci, agg * agg, 0));
+      }
+      // util::cyclic_to_local (util.hpp:131-164): this rank's element-cyclic piece of both factors
+      to_blocked(blocked, cyc);
+      unpack_piece(blocked + me * piece, Rb);
+      to_blocked(blocked, cyci);
+      unpack_piece(blocked + me * piece, Ib);
+    } else {
+      // NoReplication (policy.h:307-414) / NoReplicationOverlap (:416-514): layer 0 gathers the pieces on the slice's rank 0,
+      // which alone factors the aggregate and scatters the pieces of R and of R^-1; every rank then hands its two pieces down
+      // its depth fibre.  Overlap: R's pieces are scattered (stream 1) WHILE the root inverts (compute stream) -- the
+      // reference's MPI_Iscatter around trtri (:470-488).
+      const bool root = worker && me == 0;
+      double *blocked = nullptr, *cyc = nullptr, *cyci = nullptr;
+      if (root) { blocked = ws.take(piece * d * d); cyc = ws.take(agg * agg); cyci = ws.take(agg * agg); }
+      double* blockedi = (root && BP::overlap) ? ws.take(piece * d * d) : blocked;         // R's pieces are still in flight while R^-1's are cut
+      if (worker) {
+        pack_piece(Rb, mine);
+        CAPITAL_CHECK(capi_gather(t.slice, mine, blocked, piece, 0));                      // C6, policy.h:322-332
+        if (!BP::overlap) {
+          if (root) {
+            to_cyclic(blocked, cyc);
+            capital::dev_zero(cyci, agg * agg);
+            CAPITAL_CHECK(capi_dpotrf_trtri(h, span, cyc, agg, cyci, agg));                // :353,367 (the two scatters carry finished factors)
+            to_blocked(blocked, cyc);
+          }
+          CAPITAL_CHECK(capi_scatter(t.slice, blocked, mine, piece, 0));                   // :361-365
+          if (root) to_blocked(blocked, cyci);
+          CAPITAL_CHECK(capi_scatter(t.slice, blocked, minei, piece, 0));                  // :373-377
+        } else {
+          if (root) {
+            to_cyclic(blocked, cyc);
+            CAPITAL_CHECK(capi_dpotrf(h, CAPI_UPPER, span, cyc, agg));                     // :462
+            capital::dev_zero(cyci, agg * agg);
+            CAPITAL_CHECK(capi_dlacpy(h, 1, span, span, cyc, agg, cyci, agg));             // :463 (memcpy to scratch; upper part is all trtri reads)
+            to_blocked(blocked, cyc);
+          }
+          // every rank of the slice posts the scatter of R on stream 1, behind what the compute stream has queued so far
+          CAPITAL_CHECK(capi_event_record(h, EV_BC_POTRF));
+          CAPITAL_CHECK(capi_stream_select(h, 1));
+          CAPITAL_CHECK(capi_event_wait(h, EV_BC_POTRF));
+          CAPITAL_CHECK(capi_scatter(t.slice, blocked, mine, piece, 0));                   // :470-474 (MPI_Iscatter)
+          CAPITAL_CHECK(capi_event_record(h, EV_BC_SCATTER));
+          CAPITAL_CHECK(capi_stream_select(h, 0));
+          if (root) {
+            CAPITAL_CHECK(capi_dtrtri(h, CAPI_UPPER, CAPI_NONUNIT, span, cyci, agg));      // :476, beside the scatter
+            CAPITAL_CHECK(capi_dtrizero(h, CAPI_UPPER, agg, cyci, agg));
+            to_blocked(blockedi, cyci);
+          }
+          // one communicator, one stream at a time: the second scatter is issued only behind the first (MPI_Wait, :488)
+          CAPITAL_CHECK(capi_event_wait(h, EV_BC_SCATTER));
+          CAPITAL_CHECK(capi_scatter(t.slice, blockedi, minei, piece, 0));                 // :480-484
+        }
+      }
+      CAPITAL_CHECK(capi_bcast(t.depth, mine, piece, 0));                                  // C7, policy.h:398-399,491,505: own pieces travel
+      CAPITAL_CHECK(capi_bcast(t.depth, minei, piece, 0));
+      unpack_piece(mine, Rb);
+      unpack_piece(minei, Ib);
     }
-    if (!BP::every_layer) {                                                              // C7
-      CAPITAL_CHECK(capi_bcast(t.depth, cyc, agg * agg, 0));
-      CAPITAL_CHECK(capi_bcast(t.depth, cyci, agg * agg, 0));
-    }
-    // util::cyclic_to_local (util.hpp:131-164): this rank's element-cyclic piece of both factors
-    const int64_t me = (int64_t)t.x + d * (int64_t)t.y;
-    util::cyclic_to_block_rect(blocked, cyc, localDim, localDim, d);
-    CAPITAL_CHECK(capi_dlacpy(h, 0, localDim, localDim, blocked + me * piece, localDim, Rb, ld));
-    util::cyclic_to_block_rect(blocked, cyci, localDim, localDim, d);
-    CAPITAL_CHECK(capi_dlacpy(h, 0, localDim, localDim, blocked + me * piece, localDim, Ib, ld));
     ws.top = mark;
   }
 };

@@ -64,6 +64,7 @@ def lib():
         L.orc_block_to_cyclic_rect.argtypes = [_dp, _dp, _i64, _i64, _i64]
         L.orc_cyclic_to_block_rect.argtypes = [_dp, _dp, _i64, _i64, _i64]
         L.orc_block_to_cyclic_triangle.argtypes = [_dp, _dp, _i64, _i64, _i64, _i64]
+        L.orc_cyclic_to_block_triangle.argtypes = [_dp, _dp, _i64, _i64, _i64, _i64]
         L.orc_cyclic_to_local.argtypes = [_dp, _dp, _i64, _i64, _i64, _i64]
         L.orc_cyclic_extract.argtypes = [_dp, _i64, _i64, _i64, _dp, _i64, _i64, _i64, _i64]
         L.orc_cyclic_insert.argtypes = [_dp, _i64, _i64, _i64, _dp, _i64, _i64, _i64, _i64]

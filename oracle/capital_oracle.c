@@ -647,6 +647,27 @@ void orc_block_to_cyclic_triangle(const double* blocked, double* cyclic, int64_t
   }
   for (int64_t i = 0; i < cg; ++i) for (int64_t j = i + 1; j < rg; ++j) cyclic[i * rg + j] = 0.;
 }
+/* util::cyclic_to_block_triangle (util.hpp:167-201): the inverse walk -- every packed entry of every piece is written.
+ * Entries on a piece's local diagonal that lie below the aggregate's diagonal (x < y) receive 0; the reference skips them
+ * (they keep whatever the buffer held), and it zeroes the SOURCE as it reads, which is not restated: the source is const here. */
+void orc_cyclic_to_block_triangle(double* blocked, const double* cyclic, int64_t num_elems, int64_t rl, int64_t cl, int64_t d) {
+  int64_t rg = rl * d, offset = num_elems / (d * d), off3 = d * offset;
+  int64_t off1 = 0;
+  for (int64_t i = 0; i < cl; ++i) {
+    off1 += i;
+    for (int64_t j = 0; j < d; ++j) {
+      int64_t off2 = j * offset + off1;
+      int64_t read_idx = (i * d + j) * rg;
+      for (int64_t k = 0; k < i; ++k)
+        for (int64_t z = 0; z < d; ++z) blocked[off2 + z * off3 + k] = cyclic[read_idx++];
+      for (int64_t z = 0; z < d; ++z) {
+        blocked[off2 + z * off3 + i] = z <= j ? cyclic[read_idx] : 0.0;
+        ++read_idx;
+      }
+    }
+  }
+}
+
 /* src/util/util.hpp:131-164: pick this rank's element-cyclic piece out of the aggregate factor
  * (in place, into the leading local_dim x local_dim corner with ld = bc_dim), zeroing below the
  * GLOBAL diagonal. */

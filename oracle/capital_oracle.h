@@ -88,6 +88,7 @@ void orc_serialize(int src_struct, int dst_struct, const double* src, int64_t sd
 void orc_block_to_cyclic_rect(const double* blocked, double* cyclic, int64_t rows_local, int64_t cols_local, int64_t d);
 void orc_cyclic_to_block_rect(double* blocked, const double* cyclic, int64_t rows_local, int64_t cols_local, int64_t d);
 void orc_block_to_cyclic_triangle(const double* blocked, double* cyclic, int64_t num_elems, int64_t rows_local, int64_t cols_local, int64_t d);
+void orc_cyclic_to_block_triangle(double* blocked, const double* cyclic, int64_t num_elems, int64_t rows_local, int64_t cols_local, int64_t d);
 void orc_cyclic_to_local(double* T, double* TI, int64_t local_dim, int64_t bc_dim, int64_t d, int64_t slice_rank);
 /* element-cyclic ownership (src/matrix/matrix.hpp:8-11): extract / scatter one rank's block */
 void orc_cyclic_extract(const double* global, int64_t gcols, int64_t grows, int64_t ldg,

@@ -15,6 +15,22 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+def cpu_share():
+    """Cores this process may actually use: the cgroup's CPU quota when there is one, else the affinity mask -- capped at 16, a
+    one-GPU box's share of its host (the mask there lists all 128 hardware threads; 128 MKL threads on a 16-core share ran
+    the n = 16384 schedule at 0.09 TFLOP/s).  CAPITAL_CPU_THREADS overrides."""
+    if os.environ.get("CAPITAL_CPU_THREADS"):
+        return int(os.environ["CAPITAL_CPU_THREADS"])
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return min(n, 16)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=16384)
@@ -26,7 +42,7 @@ def main():
     a = ap.parse_args()
     import oracle as O
     O.build()
-    threads = a.threads or len(os.sched_getaffinity(0))
+    threads = a.threads or cpu_share()
     O.set_threads(threads)
     lib = None if a.no_host_blas else O.bind_host_blas(threads)
     out = {"kind": "host-blas" if lib else "port", "cores": threads if not lib else lib["threads"],

@@ -164,6 +164,14 @@ int capi_cyclic_to_block(capi_handle_t, double* blocked, const double* cyclic, i
   orc_cyclic_to_block_rect(blocked, cyclic, rl, cl, d);
   return 0;
 }
+int capi_block_to_cyclic_tri(capi_handle_t, const double* blocked, double* cyclic, int64_t rl, int64_t d) {
+  orc_block_to_cyclic_triangle(blocked, cyclic, d * d * (rl * (rl + 1) / 2), rl, rl, d);
+  return 0;
+}
+int capi_cyclic_to_block_tri(capi_handle_t, double* blocked, const double* cyclic, int64_t rl, int64_t d) {
+  orc_cyclic_to_block_triangle(blocked, cyclic, d * d * (rl * (rl + 1) / 2), rl, rl, d);
+  return 0;
+}
 int capi_distribute_symmetric(capi_handle_t, double* data, int64_t dimX, int64_t dimY, int64_t gX, int64_t gY, int64_t px, int64_t py,
                               int64_t PX, int64_t PY, int64_t key, int dd) {
   orc_distribute_symmetric(data, dimX, dimY, gX, gY, px, py, PX, PY, key, dd);

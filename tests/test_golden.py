@@ -69,3 +69,73 @@ def test_gpu_cacqr_matches_golden():
         q.close()
     finally:
         driver.finalize()
+
+
+# ---- whole schedules on the reference's own arithmetic provider (MKL's cblas_*/LAPACKE_* entry points) ------------------------
+M = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "capital_mkl_schedules.npz"))
+CHOL_CASES = [(160, 0, 1, -2), (192, 1, 1, -3), (130, 1, 2, -2), (96, 1, 1, 0)]
+CQR_CASES = [(1536, 48, 2), (1000, 24, 1)]
+
+
+def _tri(n, packed):
+    T = np.zeros((n, n))
+    T[np.triu_indices(n)] = packed
+    return T
+
+
+@pytest.mark.parametrize("n,ci,split,bc", CHOL_CASES)
+def test_oracle_cholinv_matches_mkl_schedule(oracle, n, ci, split, bc):
+    """the oracle's own kernels against the same schedule run on MKL (tests/golden/make_mkl_golden.py)"""
+    key = f"chol_n{n}_ci{ci}_s{split}_bc{-bc}"
+    R, Ri, info = oracle.cholinv_factor(oracle.distribute_symmetric(n, n, 0, 0, 1, 1), ci, split, bc, 1, 1)
+    assert info == 0 and not oracle.host_blas_active()
+    for got, ref in ((R, _tri(n, M[key + "_R"])), (Ri, _tri(n, M[key + "_Rinv"]))):
+        assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
+        assert np.count_nonzero(got) == np.count_nonzero(ref)
+
+
+@pytest.mark.parametrize("m,n,variant", CQR_CASES)
+def test_oracle_cacqr_matches_mkl_schedule(oracle, m, n, variant):
+    key = f"cqr_m{m}_n{n}_v{variant}"
+    Q, R, info = oracle.cacqr_factor_1d(oracle.distribute_random(n, m, 0, 0, 1, 1, key=0), 1, variant)
+    assert info == 0
+    Rref = _tri(n, M[key + "_R"])
+    assert np.abs(R - Rref).max() <= 1e-12 * np.abs(Rref).max()
+    assert np.abs(Q - M[key + "_Q"]).max() <= 1e-12 * (1 if variant == 2 else 50)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,ci,split,bc", CHOL_CASES)
+def test_gpu_cholinv_matches_mkl_schedule(n, ci, split, bc):
+    from capital_amd import driver
+    driver.init(0, 0, 1, None, use_torch_stream=False)
+    try:
+        key = f"chol_n{n}_ci{ci}_s{split}_bc{-bc}"
+        for serialize in (True, False):
+            p = driver.Cholinv(n, c=1, complete_inv=ci, split=split, bc_mult=bc, serialize=serialize, bc_policy=2)
+            p.generate()
+            p.factor()
+            for got, ref in ((p.R(), _tri(n, M[key + "_R"])), (p.Rinv(), _tri(n, M[key + "_Rinv"]))):
+                assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
+                assert np.count_nonzero(got) == np.count_nonzero(ref)
+            p.close()
+    finally:
+        driver.finalize()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,n,variant", CQR_CASES)
+def test_gpu_cacqr_matches_mkl_schedule(m, n, variant):
+    from capital_amd import driver
+    driver.init(0, 0, 1, None, use_torch_stream=False)
+    try:
+        key = f"cqr_m{m}_n{n}_v{variant}"
+        q = driver.Cacqr(m, n, c=1, variant=variant)
+        q.generate()
+        q.factor()
+        Rref = _tri(n, M[key + "_R"])
+        assert np.abs(q.R() - Rref).max() <= 1e-12 * np.abs(Rref).max()
+        assert np.abs(q.Q() - M[key + "_Q"]).max() <= 1e-12 * (1 if variant == 2 else 50)
+        q.close()
+    finally:
+        driver.finalize()

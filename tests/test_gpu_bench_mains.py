@@ -55,7 +55,16 @@ def test_bench_cacqr_cli(oracle):
     assert abs(res - oracle.qr_residual(A, Q, R)) <= 5e-16
 
 
-def test_bench_summa_gemm_cli():
-    out = _run("bench_summa_gemm", 512, 384, 640, 1, 0, 0, 2)
+def test_bench_summa_gemm_cli(oracle, tmp_path, monkeypatch):
+    """bench/matmult/summa_gemm.cpp:7-54: same CLI and generators; the product it leaves in C equals A B of the oracle's
+    generators elementwise (1e-12 relative), not merely "some time was printed" """
+    M, N, K = 512, 384, 640
+    monkeypatch.setenv("CAPITAL_BENCH_DUMP", str(tmp_path / "C"))
+    out = _run("bench_summa_gemm", M, N, K, 1, 0, 0, 2)
     times = [float(x) for x in re.findall(r"^total time - ([0-9.eE+-]+)", out, re.M)]
     assert len(times) == 2 and all(t > 0 for t in times)
+    C = np.fromfile(str(tmp_path / "C.0"), dtype=np.float64).reshape((M, N), order="F")
+    A = oracle.distribute_random(K, M, 0, 0, 1, 1, key=0)          # A is M x K, keyed rank / c = 0
+    B = oracle.distribute_random(N, K, 0, 0, 1, 1, key=0)          # B keyed -(rank / c) = 0 as well (summa_gemm.cpp:36-37)
+    ref = oracle.dgemm(0, 0, 1.0, A, B, 0.0, np.zeros((M, N), order="F"))
+    assert np.abs(C - ref).max() <= 1e-12 * np.abs(ref).max()

@@ -152,3 +152,30 @@ def test_two_streams_and_events(hip, oracle):
     hip.sync()
     # y: 1 -> 2 | 3 -> 6 | 7 -> 14 ; z follows y before the doubling
     assert float(y[0]) == 14.0 and float(y[-1]) == 14.0 and float(z[12345]) == 7.0
+
+
+@pytest.mark.parametrize("rl,d", [(8, 2), (5, 3), (16, 1), (33, 2)])
+def test_block_cyclic_triangle(hip, oracle, rl, d):
+    """packed-triangle pieces (util.hpp:57-102,167-201): device kernels bit-exact against the oracle's restatement, and a round
+    trip through the aggregate restores every packed entry that lies in the aggregate's upper triangle"""
+    import ctypes as C
+    import torch
+    from capital_amd import capi
+    psz = rl * (rl + 1) // 2
+    rng = np.random.default_rng(rl * 7 + d)
+    blocked = rng.uniform(0.5, 1.5, size=psz * d * d)
+    ref = np.zeros((rl * d) * (rl * d))
+    dp = C.POINTER(C.c_double)
+    oracle.lib().orc_block_to_cyclic_triangle(blocked.ctypes.data_as(dp), ref.ctypes.data_as(dp), blocked.size, rl, rl, d)
+    db = torch.from_numpy(blocked).cuda()
+    dc = torch.full((ref.size,), -3.0, dtype=torch.float64, device="cuda")          # every entry of the aggregate must be written
+    hip.call("capi_block_to_cyclic_tri", capi.ptr(db), capi.ptr(dc), rl, d)
+    np.testing.assert_array_equal(dc.cpu().numpy(), ref)
+    back = np.full(blocked.size, -5.0)
+    oracle.lib().orc_cyclic_to_block_triangle(back.ctypes.data_as(dp), ref.ctypes.data_as(dp), blocked.size, rl, rl, d)
+    db2 = torch.full((blocked.size,), -9.0, dtype=torch.float64, device="cuda")      # every packed entry must be written
+    hip.call("capi_cyclic_to_block_tri", capi.ptr(db2), capi.ptr(dc), rl, d)
+    got = db2.cpu().numpy()
+    np.testing.assert_array_equal(got, back)
+    changed = np.nonzero(got != blocked)[0]
+    assert len(changed) == rl * (d * (d - 1) // 2) and np.all(got[changed] == 0.0)   # local diagonals of the pieces with y > x

@@ -1,0 +1,134 @@
+"""N > 1 on hardware: the GPU twin of tests/test_multirank_gloo.py.  N fresh child processes, one per GPU (the parent makes no
+GPU call for them: `torch.cuda.device_count()` does not initialise the runtime on this image), each running the PRODUCT --
+RCCL world communicator from a shipped unique id, topo::square / topo::rect splits (topology.h:67-143), SUMMA broadcasts and
+depth all-reduces (summa.hpp:163-254), base-case gathers (policy.h:160-514), the partner exchange (util.hpp:232-247), the
+chunked pipeline on a second stream, the CQR2 Gram all-reduce (cacqr/policy.h:18-24).  The assembled factors must equal the
+1-rank oracle: R of an SPD matrix is unique.  Skips (per case) when the box has fewer GPUs than the case needs; the one-rank
+case runs everywhere and sends even a 1-rank communicator through RCCL (CAPI_RCCL_FORCE), so the script itself is always exercised."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _launch(world, cfg, timeout=900):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   GLOO_SOCKET_IFNAME="lo", HSA_ENABLE_IPC_MODE_LEGACY="0", CAPITAL_MIN_CHUNK_COLS="64")
+        if world == 1:
+            env["CAPI_RCCL_FORCE"] = "1"
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_gpu_rank_main.py"), json.dumps(cfg)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    try:
+        for p in procs:
+            o, _ = p.communicate(timeout=timeout)
+            outs.append(o)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
+
+
+# N -> c of the d x d x c grid: 1 = 1x1x1, 2 = 1x1x2 (K-slicing), 4 = 2x2x1 (two K-classes per layer), 8 = 2x2x2 (the reference's cubic case)
+GRID_C = {1: 1, 2: 2, 4: 1, 8: 2}
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_cholinv_and_cacqr2_on_rccl(oracle, world):
+    if _gpus() < world:
+        pytest.skip(f"needs {world} GPUs, this box has {_gpus()}")
+    c = GRID_C[world]
+    n, m_loc, nq = 4096, 1 << 15, 256
+    cases = [
+        {"tag": "ch_p0", "kind": "cholinv", "n": n, "c": c, "bc": -3, "ci": 1, "serialize": True, "policy": 0},
+        {"tag": "ch_p2", "kind": "cholinv", "n": n + 40, "c": c, "bc": -3, "ci": 0, "serialize": False, "policy": 2},      # padded blocks
+        {"tag": "ch_p3", "kind": "cholinv", "n": n, "c": c, "bc": -2, "ci": 1, "serialize": True, "policy": 3},
+        {"tag": "ch_p1", "kind": "cholinv", "n": n, "c": c, "bc": -3, "ci": 1, "serialize": False, "policy": 1},
+        {"tag": "ch_chunks", "kind": "cholinv", "n": n, "c": c, "bc": -3, "ci": 1, "serialize": True, "policy": 0, "chunks": 3},
+        {"tag": "qr", "kind": "cacqr", "m": m_loc * world, "n": nq, "serialize": True},
+    ]
+    if world == 8:
+        cases.append({"tag": "qr3d", "kind": "cacqr", "m": 1 << 14, "n": 512, "c": 2, "ci": 1, "bc": -1, "serialize": False})
+        cases.append({"tag": "ch_l1", "kind": "cholinv", "n": n, "c": c, "bc": -3, "ci": 1, "serialize": False, "policy": 0, "layout": 1})
+    with tempfile.TemporaryDirectory() as d:
+        _launch(world, {"dir": d, "cases": cases})
+        for case in cases:
+            tag = case["tag"]
+            if case["kind"] == "cholinv":
+                nn = case["n"]
+                Rg, Ig = np.zeros((nn, nn), order="F"), np.zeros((nn, nn), order="F")
+                by_xy = {}
+                for r in range(world):
+                    z = np.load(os.path.join(d, f"{tag}_rank{r}.npz"))
+                    x, y, zz, dd, cc = [int(v) for v in z["xyz"]]
+                    assert dd * dd * cc == world and cc == c
+                    assert float(z["residual"]) <= 1e-14, (tag, r, float(z["residual"]))
+                    by_xy.setdefault((x, y), []).append((z["R"], z["Rinv"]))
+                    if zz == 0:
+                        oracle.cyclic_insert(Rg, np.asfortranarray(z["R"]), x, y, dd, dd)
+                        oracle.cyclic_insert(Ig, np.asfortranarray(z["Rinv"]), x, y, dd, dd)
+                for reps in by_xy.values():                       # depth replicas hold the same blocks
+                    for other in reps[1:]:
+                        assert np.abs(other[0] - reps[0][0]).max() <= 1e-13 * np.abs(reps[0][0]).max()
+                A = oracle.distribute_symmetric(nn, nn, 0, 0, 1, 1)
+                Rref, Iref, info = oracle.cholinv_factor(A, case["ci"], 1, case["bc"], c, dd)
+                assert info == 0
+                assert np.abs(Rg - Rref).max() <= 1e-12 * np.abs(Rref).max(), tag
+                assert np.abs(Ig - Iref).max() <= 1e-12 * np.abs(Iref).max(), tag
+                assert np.count_nonzero(np.tril(Rg, -1)) == 0
+            elif case.get("c", 1) == 1:
+                m, nq_ = case["m"], case["n"]
+                Ag, Qg = np.zeros((m, nq_), order="F"), np.zeros((m, nq_), order="F")
+                Rs = []
+                for r in range(world):
+                    z = np.load(os.path.join(d, f"{tag}_rank{r}.npz"))
+                    np.testing.assert_array_equal(z["A"], oracle.distribute_random(nq_, m, 0, r, 1, world, key=r))
+                    oracle.cyclic_insert(Ag, np.asfortranarray(z["A"]), 0, r, 1, world)
+                    oracle.cyclic_insert(Qg, np.asfortranarray(z["Q"]), 0, r, 1, world)
+                    Rs.append(z["R"])
+                    assert float(z["residual"]) <= 1e-14 and float(z["orth"]) <= 1e-15
+                for Rr in Rs[1:]:
+                    np.testing.assert_array_equal(Rr, Rs[0])      # R is replicated: same all-reduced Gram, same replicated factorisation
+                Qref, Rref, info = oracle.cacqr_factor_1d(Ag, world, 2)
+                assert info == 0
+                assert np.abs(Rs[0] - Rref).max() <= 1e-12 * np.abs(Rref).max()
+                assert np.abs(Qg - Qref).max() <= 1e-12
+            else:
+                m, nq_, cc, dd = case["m"], case["n"], 2, 2
+                Ag, Qg, Rg = np.zeros((m, nq_), order="F"), np.zeros((m, nq_), order="F"), np.zeros((nq_, nq_), order="F")
+                for r in range(world):
+                    z = np.load(os.path.join(d, f"{tag}_rank{r}.npz"))
+                    x, y, zz = (r % (cc * cc)) // cc, r // (cc * cc), r % cc            # topology.h:46-50
+                    if zz == 0:
+                        oracle.cyclic_insert(Ag, np.asfortranarray(z["A"]), x, y, cc, dd)
+                        oracle.cyclic_insert(Qg, np.asfortranarray(z["Q"]), x, y, cc, dd)
+                        oracle.cyclic_insert(Rg, np.asfortranarray(z["R"]), x, y, cc, cc)
+                Qref, Rref, info = oracle.cacqr_factor_1d(Ag, 1, 2)
+                assert info == 0
+                assert np.abs(Rg - Rref).max() <= 1e-12 * np.abs(Rref).max()
+                assert np.abs(Qg - Qref).max() <= 1e-12

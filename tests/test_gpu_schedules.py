@@ -163,3 +163,25 @@ def test_factor_reports_a_non_spd_input(drv, oracle):
     with pytest.raises(DriverError, match="not positive definite|rank deficient"):
         q.factor()
     q.close()
+
+
+@pytest.mark.parametrize("serialize", (True, False))
+@pytest.mark.parametrize("n,bc,split", [(512, -1, 1), (1000, -3, 1), (2048, -3, 1), (768, -3, 2), (4608, -3, 1)])
+def test_cholinv_trsm_mode_gives_the_same_R(drv, oracle, n, bc, split, serialize):
+    """TRSM mode (info::solve_with_trsm; BASELINE north_star's POTRF + block TRSM + SYRK): the same factor R as the
+    reference-exact schedule and the oracle, no inverse formed."""
+    from capital_amd.driver import DriverError
+    p = drv.Cholinv(n, c=1, complete_inv=0, split=split, bc_mult=bc, serialize=serialize, trsm_mode=True)
+    p.generate()
+    A = p.A()
+    p.factor()
+    R = p.R()
+    Rref, _, info = oracle.cholinv_factor(A, 0, split, bc, 1, 1)
+    assert info == 0
+    assert np.abs(R - Rref).max() <= 1e-12 * np.abs(Rref).max()
+    assert np.all(np.tril(R, -1) == 0)
+    assert p.residual() <= 1e-14
+    assert p.stats()["bc_dimension"] == oracle.cholinv_bc_dimension(n, 1, 1, bc)
+    with pytest.raises(DriverError, match="no inverse"):
+        p.Rinv()
+    p.close()

@@ -229,7 +229,7 @@ def test_uid_rendezvous_survives_stale_files(shim_lib, tmp_path):
     open(base, "wb").write(bytes(128 + 8 * 3))
     for r in (1, 2):
         open(f"{base}.hello.{r}", "wb").write(b"\x01" * 8)
-        open(f"{base}.ack.{r}", "wb").write(b"\x01" * 8)
+        open(f"{base}.ack.{r}", "wb").write(b"\x01" * 16)          # same token as the stale hello: what one crashed launch leaves
     first = launch(3, keep=True)
     assert all(rc == 0 for rc, _, _ in first), first
     ids1 = {o for _, o, _ in first}

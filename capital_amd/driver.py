@@ -130,9 +130,11 @@ class Cholinv:
     """cholesky::cholinv<SP,SaveIntermediates,BP>::factor on this process's block of an n x n SPD matrix.
     Arguments in the order of the reference bench (bench/cholesky/cholinv.cpp:15-22)."""
 
-    def __init__(self, n, c=1, complete_inv=0, split=1, bc_mult=0, layout=0, num_chunks=0, serialize=True, bc_policy=2, trsm_mode=False):
+    def __init__(self, n, c=1, complete_inv=0, split=1, bc_mult=0, layout=0, num_chunks=0, serialize=True, bc_policy=2, trsm_mode=False,
+                 flush_intermediates=False):
         self.D = load()
-        self.p = self.D.capital_cholinv_create(n, c, layout, num_chunks, int(complete_inv), split, bc_mult, int(serialize), bc_policy)
+        self.p = self.D.capital_cholinv_create(n, c, layout, num_chunks, int(complete_inv), split, bc_mult,
+                                               int(bool(serialize)) + (2 if flush_intermediates else 0), bc_policy)
         if not self.p:
             raise DriverError("capital_cholinv_create: " + self.D.capital_drv_last_error().decode())
         if trsm_mode:      # info::solve_with_trsm: potrf + block TRSM + SYRK, no inverse formed (not the reference's schedule)

@@ -63,14 +63,14 @@ struct cholinv_impl : cholinv_problem {
   void set_trsm_mode(bool on) override { pack.solve_with_trsm = on; }
 };
 
-template <class SP>
+template <class SP, class IP>
 cholinv_problem* make_cholinv(int bc_policy, int64_t n, int c, int layout, int chunks, int ci, int split, int bcm) {
   namespace P = cholesky::policy::cholinv;
   switch (bc_policy) {
-    case 0: return new cholinv_impl<cholesky::cholinv<SP, P::SaveIntermediates, P::ReplicateCommComp>>(n, c, layout, chunks, ci, split, bcm);
-    case 1: return new cholinv_impl<cholesky::cholinv<SP, P::SaveIntermediates, P::ReplicateComp>>(n, c, layout, chunks, ci, split, bcm);
-    case 2: return new cholinv_impl<cholesky::cholinv<SP, P::SaveIntermediates, P::NoReplication>>(n, c, layout, chunks, ci, split, bcm);
-    case 3: return new cholinv_impl<cholesky::cholinv<SP, P::SaveIntermediates, P::NoReplicationOverlap>>(n, c, layout, chunks, ci, split, bcm);
+    case 0: return new cholinv_impl<cholesky::cholinv<SP, IP, P::ReplicateCommComp>>(n, c, layout, chunks, ci, split, bcm);
+    case 1: return new cholinv_impl<cholesky::cholinv<SP, IP, P::ReplicateComp>>(n, c, layout, chunks, ci, split, bcm);
+    case 2: return new cholinv_impl<cholesky::cholinv<SP, IP, P::NoReplication>>(n, c, layout, chunks, ci, split, bcm);
+    case 3: return new cholinv_impl<cholesky::cholinv<SP, IP, P::NoReplicationOverlap>>(n, c, layout, chunks, ci, split, bcm);
   }
   throw std::invalid_argument("base-case policy id must be 0..3 (policy.h get_id)");
 }
@@ -159,12 +159,16 @@ int capital_drv_world_query(int* rank, int* size) {
   });
 }
 
+// serialize_: 0 NoSerialize, 1 Serialize; + 2: FlushIntermediates instead of SaveIntermediates (policy.h:21-156)
 void* capital_cholinv_create(int64_t n, int c, int layout, int num_chunks, int complete_inv, int split, int bc_mult, int serialize_, int bc_policy) {
   cholinv_problem* p = nullptr;
   int rc = guarded([&] {
     namespace P = cholesky::policy::cholinv;
-    p = serialize_ ? make_cholinv<P::Serialize>(bc_policy, n, c, layout, num_chunks, complete_inv, split, bc_mult)
-                   : make_cholinv<P::NoSerialize>(bc_policy, n, c, layout, num_chunks, complete_inv, split, bc_mult);
+    const bool ser = (serialize_ & 1) != 0, flush = (serialize_ & 2) != 0;
+    if (ser && flush) p = make_cholinv<P::Serialize, P::FlushIntermediates>(bc_policy, n, c, layout, num_chunks, complete_inv, split, bc_mult);
+    else if (ser) p = make_cholinv<P::Serialize, P::SaveIntermediates>(bc_policy, n, c, layout, num_chunks, complete_inv, split, bc_mult);
+    else if (flush) p = make_cholinv<P::NoSerialize, P::FlushIntermediates>(bc_policy, n, c, layout, num_chunks, complete_inv, split, bc_mult);
+    else p = make_cholinv<P::NoSerialize, P::SaveIntermediates>(bc_policy, n, c, layout, num_chunks, complete_inv, split, bc_mult);
   });
   return rc ? nullptr : p;
 }

@@ -169,7 +169,14 @@ public:
         serialize<uppertri, uppertri>::invoke(args.Rinvfull, args.Rinv, 0, ld, 0, ld, 0, ld, 0, ld);
       }
     }
-    if (!IP::keep_arena) { capital::sync(); args.work = matmult::arena(); }
+    if (!IP::keep_arena) {
+      // FlushIntermediates (policy.h:85-156: every level's buffers are released after use instead of cached in the tables): here
+      // the intermediates are the work arena and, with Serialize, the two full-storage working images of the factors -- after
+      // the call only what the caller asked for stays resident (n = 65536 on one GPU: 96 GiB instead of 171 GiB beside A).
+      capital::sync();
+      args.work = matmult::arena();
+      if (packed) { args.Rfull._destroy_(); args.Rinvfull._destroy_(); args.zeroed = false; }
+    }
     CRITTER_STOP(CI::factor);
     // one 4-byte read behind the whole launch chain: a non-SPD input must not come back as NaN factors with status OK
     CAPITAL_CHECK(capi_get_info(capital::handle(), &args.potrf_info));

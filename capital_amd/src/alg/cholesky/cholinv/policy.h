@@ -4,7 +4,8 @@
 //                                        triangle vs full local block).  The device recursion always works on full
 //                                        local blocks (MFMA tiles want a leading dimension); Serialize packs once at
 //                                        the end instead of packing/unpacking around every BLAS call (summa.hpp:216).
-//   SaveIntermediates / FlushIntermediates : keep or release the work arena between factor() calls.
+//   SaveIntermediates / FlushIntermediates : keep, or release after every factor() call, everything that is not a result: the
+//                                        work arena and (with Serialize) the full-storage working images of R and R^-1.
 //   ReplicateCommComp / ReplicateComp / NoReplication / NoReplicationOverlap : how a base-case diagonal block that is
 //                                        spread over the d x d slice is brought together, factored and handed back.
 // Base case on device (all four strategies end in the same R and R^-1; they differ in who computes and what travels):

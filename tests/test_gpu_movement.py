@@ -105,13 +105,17 @@ def test_block_cyclic(hip, oracle, rl, d):
     dp = C.POINTER(C.c_double)
     oracle.lib().orc_block_to_cyclic_rect(blocked.ctypes.data_as(dp), ref.ctypes.data_as(dp), rl, rl, d)
     db, dc = torch.from_numpy(blocked).cuda(), torch.zeros(ref.size, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()             # torch fills on ITS stream; the handle runs on its own
     hip.call("capi_block_to_cyclic", capi.ptr(db), capi.ptr(dc), rl, rl, d)
+    hip.sync()
     np.testing.assert_array_equal(dc.cpu().numpy(), ref)
     full = rng.uniform(size=ref.size)
     back = np.zeros_like(blocked)
     oracle.lib().orc_cyclic_to_block_rect(back.ctypes.data_as(dp), full.ctypes.data_as(dp), rl, rl, d)
     db2, dfull = torch.zeros(blocked.size, dtype=torch.float64, device="cuda"), torch.from_numpy(full).cuda()
+    torch.cuda.synchronize()
     hip.call("capi_cyclic_to_block", capi.ptr(db2), capi.ptr(dfull), rl, rl, d)
+    hip.sync()
     np.testing.assert_array_equal(db2.cpu().numpy(), back)
 
 
@@ -169,12 +173,16 @@ def test_block_cyclic_triangle(hip, oracle, rl, d):
     oracle.lib().orc_block_to_cyclic_triangle(blocked.ctypes.data_as(dp), ref.ctypes.data_as(dp), blocked.size, rl, rl, d)
     db = torch.from_numpy(blocked).cuda()
     dc = torch.full((ref.size,), -3.0, dtype=torch.float64, device="cuda")          # every entry of the aggregate must be written
+    torch.cuda.synchronize()             # torch fills on ITS stream; the handle runs on its own
     hip.call("capi_block_to_cyclic_tri", capi.ptr(db), capi.ptr(dc), rl, d)
+    hip.sync()
     np.testing.assert_array_equal(dc.cpu().numpy(), ref)
     back = np.full(blocked.size, -5.0)
     oracle.lib().orc_cyclic_to_block_triangle(back.ctypes.data_as(dp), ref.ctypes.data_as(dp), blocked.size, rl, rl, d)
     db2 = torch.full((blocked.size,), -9.0, dtype=torch.float64, device="cuda")      # every packed entry must be written
+    torch.cuda.synchronize()
     hip.call("capi_cyclic_to_block_tri", capi.ptr(db2), capi.ptr(dc), rl, d)
+    hip.sync()
     got = db2.cpu().numpy()
     np.testing.assert_array_equal(got, back)
     changed = np.nonzero(got != blocked)[0]

@@ -66,6 +66,7 @@ int capi_destroy(capi_handle_t h) {
   for (int i = 0; i < capi_handle_s::NSTREAMS; ++i) {
     if (h->ws[i]) (void)hipFree(h->ws[i]);
     if (h->ws2[i]) (void)hipFree(h->ws2[i]);
+    if (h->ws3[i]) (void)hipFree(h->ws3[i]);
   }
   if (h->d_info) (void)hipFree(h->d_info);
   if (h->h_info) (void)hipHostFree(h->h_info);
@@ -272,3 +273,4 @@ static int ws_grow(capi_handle_t h, void** slot, size_t* cap, size_t bytes, void
 }
 int capi_ws_get(capi_handle_t h, size_t bytes, void** p) { return h ? ws_grow(h, &h->ws[h->cur], &h->ws_bytes[h->cur], bytes, p) : CAPI_EINVAL; }
 int capi_ws2_get(capi_handle_t h, size_t bytes, void** p) { return h ? ws_grow(h, &h->ws2[h->cur], &h->ws2_bytes[h->cur], bytes, p) : CAPI_EINVAL; }
+int capi_ws3_get(capi_handle_t h, size_t bytes, void** p) { return h ? ws_grow(h, &h->ws3[h->cur], &h->ws3_bytes[h->cur], bytes, p) : CAPI_EINVAL; }

@@ -24,6 +24,9 @@ struct capi_handle_s {
   // second, independent scratch block (diagonal-block inverses, recursion temporaries)
   void* ws2[NSTREAMS] = {nullptr, nullptr, nullptr, nullptr};
   size_t ws2_bytes[NSTREAMS] = {0, 0, 0, 0};
+  // third block: clean copies of small triangular operands (tall right-TRMM); never aliases what callers keep in ws / ws2
+  void* ws3[NSTREAMS] = {nullptr, nullptr, nullptr, nullptr};
+  size_t ws3_bytes[NSTREAMS] = {0, 0, 0, 0};
   // device-side LAPACK info word (0 ok, >0 first bad pivot, 1-based) + pinned host mirror
   int* d_info = nullptr;
   int* h_info = nullptr;
@@ -70,5 +73,6 @@ enum { CAPI_ATTR_LEAF = 0, CAPI_ATTR_TRMM_TS32 = 1, CAPI_ATTR_TRMM_TS16 = 2, CAP
 // returns a workspace pointer of at least `bytes` (stream-ordered reuse: callers run on h->stream)
 int capi_ws_get(capi_handle_t h, size_t bytes, void** p);
 int capi_ws2_get(capi_handle_t h, size_t bytes, void** p);
+int capi_ws3_get(capi_handle_t h, size_t bytes, void** p);
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

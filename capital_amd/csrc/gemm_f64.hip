@@ -87,6 +87,8 @@ struct GemmArgs {
   int ts;             // tile size chosen by the launcher
   int no_skip;        // diagnostics: never skip zero sub-tiles
   int share_ab;       // A and B are the same matrix in the same orientation (syrk): diagonal tiles stage ONE panel
+  int tri_dense;      // the triangular operand is a clean copy whose other triangle holds zeros: the panels that cross its diagonal
+                      // need neither masking nor sub-tile bookkeeping and run in the FAST loop (tall right-TRMM, see trmm_launch)
 };
 
 // ---- global -> registers: this thread's 4 x 16 bytes of a 128 x 16 operand panel -----------------
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel
     khi = min(khi, (z + 1) * p.k_per_split);
   }
   const int ntk = khi > klo ? (khi - klo + kstep - 1) / kstep : 0;
-  const bool maskA = p.tri_side == CAPI_LEFT, maskB = p.tri_side == CAPI_RIGHT;
+  const bool maskA = p.tri_side == CAPI_LEFT && !p.tri_dense, maskB = p.tri_side == CAPI_RIGHT && !p.tri_dense;
   const bool shareB = AK == BKC && p.share_ab && ti == tj;   // B panel == A panel: load and stage it once
   const bool keep_ge = (p.tri_side == CAPI_LEFT) == (p.tri_eff_upper != 0);
 
@@ -399,7 +401,7 @@ __global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel
       const int kk = klo + t * kstep;
       // only panels that cross the diagonal band of this tile can have dead sub-tiles
       const bool band = p.tri_side == CAPI_LEFT ? (kk < i0 + BM && kk + BK > i0) : (kk < j0 + BN && kk + BK > j0);
-      if (p.tri_side >= 0 && band && !p.no_skip) {
+      if (p.tri_side >= 0 && band && !p.no_skip && !p.tri_dense) {
 #pragma unroll
         for (int a = 0; a < SUB; ++a)
 #pragma unroll
@@ -477,7 +479,7 @@ __global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel
   //  skipping them in the generic one -- the wave holding 16 live sub-tiles sets the pace either way)
   const int nfast = (interior && khi - klo >= BK) ? (khi - klo - BK) / kstep : 0;
   int tb0 = ntk, tb1 = ntk;                 // no band
-  if (p.tri_side >= 0) {
+  if (p.tri_side >= 0 && !p.tri_dense) {
     const int d0 = p.tri_side == CAPI_LEFT ? i0 : j0;
     tb0 = d0 > klo ? (d0 - klo) / BK : 0;
     tb1 = d0 + TS > klo ? (d0 + TS - klo + BK - 1) / BK : 0;
@@ -1628,6 +1630,23 @@ static int trmm_launch(capi_handle_t h, int side, int uplo, int trans, int diag,
   p.tri_side = side;
   p.tri_eff_upper = ((uplo == CAPI_UPPER) != (trans == CAPI_TRANS));
   p.tri_unit = diag == CAPI_UNIT;
+  // Tall right-TRMM (CholeskyQR2's Q = A R^-1 at n = 512..2048; config 5 is 2^23 x 1024 per GPU): every column tile's k-range ends in
+  // eight panels that cross T's diagonal, which the kernel's generic loop masks and prunes one by one -- a fifth of all
+  // iterations at n = 1024.  Here T's triangle is copied ONCE into a zeroed n x n block of the handle (8 MiB at n = 1024, read
+  // by every tile anyway) and the kernel is told the other triangle holds zeros: all iterations take the lean loop; the k-range
+  // of a tile is still cut at its diagonal block, the other triangle of the CALLER's T is still never read.
+  static const bool no_tall = getenv("CAPI_NO_TALL") != nullptr;
+  if (!no_tall && side == CAPI_RIGHT && diag == CAPI_NONUNIT && n >= 512 && n <= 4096 && m >= 64 * n) {
+    void* w;
+    int rc = capi_ws3_get(h, sizeof(double) * (size_t)n * (size_t)n, &w);
+    if (rc != CAPI_OK) return rc;
+    CAPI_HIP_CHECK(h, hipMemsetAsync(w, 0, sizeof(double) * (size_t)n * (size_t)n, h->stream));
+    rc = capi_dlacpy(h, uplo == CAPI_UPPER ? 1 : 2, n, n, T, ldt, (double*)w, n);
+    if (rc != CAPI_OK) return rc;
+    T = (const double*)w;
+    ldt = n;
+    p.tri_dense = 1;
+  }
   if (side == CAPI_LEFT) {  // C = alpha op(T) B : A-operand = T (transA = trans), B-operand = B (NoTrans)
     p.A = T; p.lda = ldt; p.B = B; p.ldb = ldb;
     return launch_gemm(h, trans == CAPI_TRANS, true, p, ws_free);

@@ -174,7 +174,7 @@ public:
       // the intermediates are the work arena and, with Serialize, the two full-storage working images of the factors -- after
       // the call only what the caller asked for stays resident (n = 65536 on one GPU: 96 GiB instead of 171 GiB beside A).
       capital::sync();
-      args.work = matmult::arena();
+      args.work.release();
       if (packed) { args.Rfull._destroy_(); args.Rinvfull._destroy_(); args.zeroed = false; }
     }
     CRITTER_STOP(CI::factor);

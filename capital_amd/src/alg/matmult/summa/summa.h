@@ -25,7 +25,16 @@ namespace matmult {
 struct arena {
   double* base = nullptr;
   int64_t cap = 0, top = 0;
-  ~arena() { capital::dev_free(base); }
+  arena() = default;
+  arena(const arena&) = delete;                 // owns device memory: a copy would free it twice, an assignment would leak it
+  arena& operator=(const arena&) = delete;
+  arena(arena&& o) noexcept : base(o.base), cap(o.cap), top(o.top) { o.base = nullptr; o.cap = o.top = 0; }
+  arena& operator=(arena&& o) noexcept {
+    if (this != &o) { release(); base = o.base; cap = o.cap; top = o.top; o.base = nullptr; o.cap = o.top = 0; }
+    return *this;
+  }
+  ~arena() { release(); }
+  void release() { capital::dev_free(base); base = nullptr; cap = top = 0; }
   void reserve(int64_t count) {
     if (count > cap) {
       capital::sync();

@@ -1343,6 +1343,30 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
       return CAPI_OK;
     }
   }
+  // Tall-skinny Gram matrix WIDER than the full-width kernel (CholeskyQR2 at n = 512..2048; config 5: n = 1024, K = 2^23): by 256-blocks.
+  // The 128-tiling computes its diagonal tiles whole (36 tile-units for 32 at n = 1024: 11 % of the MFMAs produce the unwanted
+  // triangle).  Here the diagonal 256-blocks go to the full-width kernel below, whose 136-of-256 tile map wastes 6 % of a quarter
+  // of the work, and the off-diagonal blocks are plain 256 x 256 products A_I^T A_J on the tile kernel (split-K; the four tiles of a
+  // slice are consecutive arrivals on one XCD and share their panels in its L2).  (CAPI_NO_TALL: the plain 128-tiling, A/B.)
+  {
+    static const bool no_tall_gram = getenv("CAPI_NO_TALL") != nullptr || getenv("CAPI_NO_TS") != nullptr;
+    if (!no_tall_gram && p.out_uplo == CAPI_UPPER && p.tri_side < 0 && ak && bkc && p.A == p.B && p.lda == p.ldb && p.N > TSK_W &&
+        p.N <= 2048 && p.N % TSK_W == 0 && (int64_t)p.K >= 64 * (int64_t)p.N && ws_for_slab && p.batch <= 1) {
+      const int nb = p.N / TSK_W;
+      for (int J = 0; J < nb; ++J)
+        for (int I = 0; I <= J; ++I) {
+          GemmArgs q = p;
+          q.A = p.A + (int64_t)I * TSK_W * p.lda;
+          q.B = p.A + (int64_t)J * TSK_W * p.lda;
+          q.C = p.C + (int64_t)I * TSK_W + (int64_t)J * TSK_W * p.ldc;
+          q.M = q.N = TSK_W;
+          q.out_uplo = I == J ? CAPI_UPPER : -1;
+          int rc = launch_gemm(h, true, true, q, true);
+          if (rc != CAPI_OK) return rc;
+        }
+      return CAPI_OK;
+    }
+  }
   // tall-skinny Gram matrix: full-width workgroups, the tall operand is read once
   {
     static const bool no_ts = getenv("CAPI_NO_TS") != nullptr;
@@ -1415,7 +1439,10 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
       const double panels = (p.out_uplo >= 0 && p.A == p.B) ? 2.0 * nt - (double)cdiv(p.N, ts) : (tri ? 1.0 * nt : 2.0 * nt);
       // (operands that fit the 256 MB Infinity Cache are re-read from there at roughly twice the HBM-side rate)
       const double footprint = ((p.A == p.B ? 0.0 : (double)p.M) + (double)p.N) * (double)p.K * 8.0;
-      const double t_mem = panels * ts * keff * 8.0 / (footprint <= 192.0e6 ? 8.0e6 : 4.0e6);
+      double t_mem = panels * ts * keff * 8.0 / (footprint <= 192.0e6 ? 8.0e6 : 4.0e6);
+      // a split-K slice whose tiles all fit one XCD's resident set (<= 32 tiles: consecutive pids, started together, walking the
+      // same panels in step) shares those panels in that L2: a tall product then streams each operand about once
+      if (!tri && nt <= 32.0 && (double)p.K >= 64.0 * (double)(p.M > p.N ? p.M : p.N)) t_mem = footprint / 4.0e6;
       if (t_mem > t) t = t_mem;
       if (sk > 1) t = 1.12 * t + 6.0 + (double)(sk + 2) * (double)p.M * (double)p.N * (p.out_uplo >= 0 ? 0.5 : 1.0) * 8.0 / 2.5e6;
       if (t < best) { best = t; best_ts = ts; best_s = sk; }

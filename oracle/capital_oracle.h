@@ -18,6 +18,13 @@
  *   - K1..K9 (dgemm/dtrmm/dsyrk/dpotrf/dtrtri): against the LAPACK/BLAS the
  *     image does have (scipy's OpenBLAS, and libmkl_rt.so -- the reference's
  *     own third-party dependency -- when present);
+ *   - whole schedules: orc_host_blas_bind() routes the five BLAS/LAPACK routines
+ *     below to the cblas_* / LAPACKE_* entry points of a host library at run time;
+ *     tests/golden/make_mkl_golden.py runs cholinv and cacqr that way on Intel MKL
+ *     (the reference's arithmetic provider) and commits R, R^-1, Q as fixtures
+ *     (tests/golden/capital_mkl_schedules.npz) that this file's OWN kernels must
+ *     reproduce to 1e-12 (tests/test_golden.py).  The same binding is bench.py's
+ *     cpu_baseline (oracle/host_baseline.py);
  *   - schedules: through the reference's own validator metrics
  *     (test/cholesky/validate.hpp, test/qr/validate.hpp) and the values the
  *     survey recorded for the unmodified reference.
@@ -39,6 +46,13 @@ enum { ORC_NOTRANS = 0, ORC_TRANS = 1 };
 enum { ORC_LEFT = 0, ORC_RIGHT = 1 };
 enum { ORC_LOWER = 0, ORC_UPPER = 1 };
 enum { ORC_NONUNIT = 0, ORC_UNIT = 1 };
+
+/* host-BLAS backend: bind cblas_dgemm/dtrmm/dsyrk + LAPACKE_dpotrf/dtrtri of `path` (symbol names get prefix/suffix, e.g.
+ * "scipy_" / "64_" for numpy's bundled OpenBLAS; ilp64: 64-bit integer arguments); 0 on success.  Once bound, orc_dgemm ..
+ * orc_dtrtri forward to it (column-major, the constants of src/blas/interface.hpp:49-52) until orc_host_blas_enable(0). */
+int  orc_host_blas_bind(const char* path, const char* prefix, const char* suffix, int ilp64);
+void orc_host_blas_enable(int on);
+int  orc_host_blas_active(void);
 
 void orc_set_threads(int nthreads);
 int  orc_get_threads(void);

@@ -89,6 +89,9 @@ struct GemmArgs {
   int share_ab;       // A and B are the same matrix in the same orientation (syrk): diagonal tiles stage ONE panel
   int tri_dense;      // the triangular operand is a clean copy whose other triangle holds zeros: the panels that cross its diagonal
                       // need neither masking nor sub-tile bookkeeping and run in the FAST loop (tall right-TRMM, see trmm_launch)
+  int tri_koff;       // tri_dense, right side, upper: this launch holds columns [tri_koff, tri_koff + N) of op(T): column tile tj's k-range
+                      // ends at tri_koff + (tj + 1) TS.  Tiles are then dealt like a plain product's (tri_block)
+  int tri_block;
 };
 
 // ---- global -> registers: this thread's 4 x 16 bytes of a 128 x 16 operand panel -----------------
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel
   const int pid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
   int z = pid / p.ntiles;
   int ti, tj;
-  if (p.tri_side >= 0 && p.splitk == 1) { z = 0; trmm_tile_of(p, bid, ti, tj); }
+  if (p.tri_side >= 0 && p.splitk == 1 && !p.tri_block) { z = 0; trmm_tile_of(p, bid, ti, tj); }
   else tile_of(p, pid - z * p.ntiles, ti, tj);
   if (p.tail_base > 0) {                      // quarters outside the matrix or wholly in the unwanted triangle (uniform per workgroup)
     if (ti >= p.tiles_m || tj >= p.tiles_n) return;
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel
   if (p.tri_side == CAPI_LEFT) {
     if (p.tri_eff_upper) klo = i0; else khi = min(p.K, i0 + BM);
   } else if (p.tri_side == CAPI_RIGHT) {
-    if (p.tri_eff_upper) khi = min(p.K, j0 + BN); else klo = j0;
+    if (p.tri_eff_upper) khi = min(p.K, p.tri_koff + j0 + BN); else klo = j0;
   }
   constexpr int kstep = BK;
   if (p.splitk > 1) {
@@ -1673,6 +1676,31 @@ static int trmm_launch(capi_handle_t h, int side, int uplo, int trans, int diag,
     T = (const double*)w;
     ldt = n;
     p.tri_dense = 1;
+    // Upper op(T) and n a multiple of 256: one launch per 256-column block of the output, C_J = B(:, 0 : 256 (J + 1)) op(T)(0 : 256 (J + 1), J),
+    // tiles dealt as a plain product's (bands of 8 row tiles x the block's two column tiles per XCD).  A launch's slice of T (<= 2 MiB at
+    // n = 1024) stays in every L2 and its tiles have near-equal k-ranges: m = 2^23: 147.0 -> 142.5 ms, n = 512: 51.8 -> 56.6 TFLOP/s; block 0
+    // (K = 256) is the T-stationary kernel's shape.  B is still fetched once per column tile (FETCH_SIZE unchanged): an XCD streams
+    // 2 MiB of panels per iteration through its 4 MiB L2, so a partner tile one iteration behind already misses; making the two
+    // column tiles of a row tile consecutive arrivals was measured slower (152.7 ms).  (CAPI_TALL_ONE_LAUNCH: A/B.)
+    static const bool one_launch = getenv("CAPI_TALL_ONE_LAUNCH") != nullptr;
+    const bool eff_upper = (uplo == CAPI_UPPER) != (trans == CAPI_TRANS);
+    if (!one_launch && eff_upper && n % 256 == 0) {
+      for (int64_t J = 0; J < n / 256; ++J) {
+        GemmArgs q = p;
+        q.N = 256;
+        q.K = (int)(256 * (J + 1));
+        q.tri_koff = (int)(256 * J);
+        q.tri_block = 1;
+        q.C = C + 256 * J * ldc;
+        q.A = B; q.lda = ldb;
+        // op(T)(k, j) for k < K, j in the block: NoTrans -> T[k + j ldt] (k-contiguous), Trans -> T[j + k ldt]
+        q.B = trans == CAPI_NOTRANS ? T + 256 * J * ldt : T + 256 * J;
+        q.ldb = ldt;
+        int rc2 = launch_gemm(h, false, trans == CAPI_NOTRANS, q, ws_free);
+        if (rc2 != CAPI_OK) return rc2;
+      }
+      return CAPI_OK;
+    }
   }
   if (side == CAPI_LEFT) {  // C = alpha op(T) B : A-operand = T (transA = trans), B-operand = B (NoTrans)
     p.A = T; p.lda = ldt; p.B = B; p.ldb = ldb;

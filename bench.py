@@ -86,14 +86,15 @@ def recorded_traffic(n, gpus):
     (2 x FETCH_SIZE + WRITE_SIZE on gfx950; profiles/README.md).  Counters cannot be read from inside a timed run, so this is
     a RECORDED figure (`traffic_source` names the files), or None when no pass of this configuration is committed."""
     import csv
-    tag = {(65536, 1): "r2_pmc_{}_bench_n65536.csv", (32768, 1): "r1_d_pmc_{}_bench_step.csv"}.get((n, gpus))
+    # (file pattern, trailing rows that belong to the residual check's products rather than to factor())
+    tag, drop = {(65536, 1): ("r2_pmc_{}_bench_n65536.csv", 0), (32768, 1): ("r1_d_pmc_{}_bench_step.csv", 1)}.get((n, gpus), (None, 0))
     if tag is None:
         return None, None
     tot, launches = 0.0, 0
     try:
         for t, name in (("fe", "FETCH_SIZE"), ("wr", "WRITE_SIZE")):
             rows = [r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", tag.format(t)))) if r["Counter_Name"] == name]
-            rows = rows[:-1]        # the last launch of the pass is the residual check's product, not factor()
+            rows = rows[:len(rows) - drop]
             launches = len(rows)
             tot += sum(float(r["Counter_Value"]) for r in rows) * 1024 * (2 if name == "FETCH_SIZE" else 1)
     except (OSError, KeyError, ValueError):

@@ -12,9 +12,12 @@
 // dorgqr applies the block reflectors, last panel first, to [I; 0] in workspace and copies the result over A.
 // HBM-bound per column (the rest of the panel is read and written once per column); dlarfg's rescaling loop for subnormal
 // norms is omitted.
+#include <stdlib.h>
 #include "capi_internal.h"
 
 namespace {
+
+__global__ void set_info_kernel(int* info, int v) { *info = v; }
 
 constexpr int QNB = 32;      // block reflector width
 constexpr int QPART = 1024;  // partial-sum slots of the column reductions (= workgroups of a panel pass: 4 per CU)
@@ -281,6 +284,126 @@ int block_reflector(capi_handle_t h, const double* Apanel, int64_t lda, int64_t 
   return CAPI_OK;
 }
 
+
+// ---- tall panels: CholeskyQR2 + Householder reconstruction ------------------------------------------------------------------
+// For m >= 64 n the column-by-column panel above makes n passes over the panel (135 ms at 2^22 x 256) while CholeskyQR2 -- this
+// library's hot path -- factors the same matrix in five passes on the MFMA kernels (19 ms).  Its Q and R determine the LAPACK
+// output uniquely (Ballard, Demmel, Grigori, Jacquelin, Nguyen, Solomonik: "Reconstructing Householder vectors from TSQR", 2014):
+// with S = diag(s_i), the thin Householder factor is Q S and
+//        Q - [S; 0] = Y U,      Y unit lower trapezoidal (the reflectors), U upper triangular,
+// an LU factorisation WITHOUT pivoting in which s_i = -sign of the i-th diagonal entry at the moment it becomes the pivot -- the
+// sign dlarfg chooses, and the choice that keeps every pivot >= 1 in magnitude.  Then R_out = S R, tau_i = T_ii = -s_i U_ii
+// (T = -U S Y1^-T), and the rows below the top block are Y2 = Q2 U^-1: one more tall product.
+// Used only when CholeskyQR2 is safe: both Gram matrices factor (device info) and the first sweep's R has a diagonal ratio below 1e6
+// (kappa(A) well inside the u^-1/2 limit); otherwise A is untouched and the Householder panels above run.  n <= 2048.
+constexpr int HRNB = 32;
+
+// unblocked LU without pivoting of an (rows x nb) panel whose pivot block starts at P; sgn[c] = the sign subtracted from pivot c
+__global__ __launch_bounds__(1024) void hr_lu_panel_kernel(double* __restrict__ P, int64_t ld, int rows, int nb, double* __restrict__ sgn) {
+  __shared__ double piv;
+  for (int c = 0; c < nb; ++c) {
+    if (threadIdx.x == 0) {
+      const double d = P[c + (int64_t)c * ld];
+      const double sg = d >= 0.0 ? -1.0 : 1.0;             // -sign(d), sign(0) = +1 as in dlarfg (beta = -sign(alpha) norm)
+      P[c + (int64_t)c * ld] = d - sg;
+      sgn[c] = sg;
+      piv = d - sg;
+    }
+    __syncthreads();
+    const double inv = 1.0 / piv;                            // dlarfg scales x by 1 / (alpha - beta)
+    for (int r = c + 1 + (int)threadIdx.x; r < rows; r += (int)blockDim.x) {
+      const double l = P[r + (int64_t)c * ld] * inv;
+      P[r + (int64_t)c * ld] = l;
+      for (int cc = c + 1; cc < nb; ++cc) P[r + (int64_t)cc * ld] -= l * P[c + (int64_t)cc * ld];
+    }
+    __syncthreads();
+  }
+}
+
+// top n x n block of the output: reflectors (strictly lower part of the LU image W), R_out = S R above, tau_i = -s_i U_ii
+__global__ void hr_assemble_kernel(double* __restrict__ A, int64_t lda, const double* __restrict__ W, const double* __restrict__ R,
+                                   const double* __restrict__ sgn, int n, double* __restrict__ tau) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int j = blockIdx.y; j < n; j += gridDim.y) A[i + (int64_t)j * lda] = i > j ? W[i + (int64_t)j * n] : sgn[i] * R[i + (int64_t)j * n];
+  if (blockIdx.y == 0) tau[i] = -sgn[i] * W[i + (int64_t)i * n];
+}
+
+__global__ void hr_diag_ratio_kernel(const double* __restrict__ R, int n, double* __restrict__ out2) {   // one workgroup: min and max |r_ii|
+  __shared__ double lo[256], hi[256];
+  double a = 1e300, b = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) { const double v = fabs(R[i + (int64_t)i * n]); a = v < a ? v : a; b = v > b ? v : b; }
+  lo[threadIdx.x] = a; hi[threadIdx.x] = b;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { lo[threadIdx.x] = fmin(lo[threadIdx.x], lo[threadIdx.x + o]); hi[threadIdx.x] = fmax(hi[threadIdx.x], hi[threadIdx.x + o]); }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out2[0] = lo[0]; out2[1] = hi[0]; }
+}
+
+// returns CAPI_OK with *done = 1 when A and tau hold the factorisation, *done = 0 when the caller must take the Householder panels
+int geqrf_tall_reconstruct(capi_handle_t h, int64_t m, int64_t n, double* A, int64_t lda, double* tau, int* done) {
+  *done = 0;
+  hipStream_t s = h->stream;
+  const size_t nn = (size_t)n * (size_t)n;
+  double* buf = nullptr;                                     // own allocation: the BLAS / LAPACK calls below use the handle's workspaces
+  {
+    hipError_t e = hipMalloc((void**)&buf, sizeof(double) * (2 * (size_t)m * (size_t)n + 8 * nn + 2 * (size_t)n + 16));
+    if (e != hipSuccess) { (void)hipGetLastError(); return CAPI_OK; }      // not enough memory beside the caller's data: slow path
+  }
+  double *Q1 = buf, *Q2 = Q1 + (size_t)m * n, *G = Q2 + (size_t)m * n, *Gi = G + nn, *R1 = Gi + nn, *Rf = R1 + nn, *W = Rf + nn, *Ui = W + nn,
+         *sgn = Ui + nn + 2 * nn, *stat = sgn + n;
+  auto fail = [&](int rc) { (void)hipStreamSynchronize(s); (void)hipFree(buf); return rc; };
+  int saved_info = 0;
+#define HR(x) do { int rc__ = (x); if (rc__ != CAPI_OK) return fail(rc__); } while (0)
+  HR(capi_get_info(h, &saved_info));                         // the handle's LAPACK info word is borrowed for the two Gram factorisations
+  HR(capi_reset_info(h));
+  // sweep 1 (cacqr.hpp:7-29)
+  HR(capi_dsyrk(h, CAPI_UPPER, CAPI_TRANS, n, m, 1.0, A, lda, 0.0, G, n));
+  HR(capi_dpotrf_trtri(h, n, G, n, Gi, n));
+  HR(capi_memcpy_d2d_async(h, R1, G, sizeof(double) * nn));
+  hipLaunchKernelGGL(hr_diag_ratio_kernel, dim3(1), dim3(256), 0, s, G, (int)n, stat);
+  HR(capi_dtrmm_oop(h, CAPI_RIGHT, CAPI_UPPER, CAPI_NOTRANS, CAPI_NONUNIT, m, n, 1.0, Gi, n, A, lda, Q1, m));
+  // sweep 2 and R = R2 R1 (cacqr.hpp:181-189)
+  HR(capi_dsyrk(h, CAPI_UPPER, CAPI_TRANS, n, m, 1.0, Q1, m, 0.0, G, n));
+  HR(capi_dpotrf_trtri(h, n, G, n, Gi, n));
+  HR(capi_dtrmm_oop(h, CAPI_RIGHT, CAPI_UPPER, CAPI_NOTRANS, CAPI_NONUNIT, m, n, 1.0, Gi, n, Q1, m, Q2, m));
+  HR(capi_dtrmm_oop(h, CAPI_RIGHT, CAPI_UPPER, CAPI_NOTRANS, CAPI_NONUNIT, n, n, 1.0, R1, n, G, n, Rf, n));
+  int info = 0;
+  HR(capi_get_info(h, &info));                               // synchronises
+  double st[2];
+  HR(capi_memcpy_d2h(h, st, stat, sizeof(st)));
+  if (saved_info) {                                          // give the caller's pending info back (first failure wins, as on the device)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(set_info_kernel), dim3(1), dim3(1), 0, s, h->d_info, saved_info);
+  } else {
+    HR(capi_reset_info(h));
+  }
+  if (info != 0 || !(st[0] > 0.0) || st[1] / st[0] > 1e6) return fail(CAPI_OK);      // CholeskyQR2 is not safe here: Householder panels
+  // LU without pivoting of the top block of Q (blocked right-looking: panel, U12 = L11^-1 A12, A22 -= L21 U12)
+  HR(capi_dlacpy(h, 0, n, n, Q2, m, W, n));
+  for (int64_t j0 = 0; j0 < n; j0 += HRNB) {
+    const int nb = (int)(n - j0 < HRNB ? n - j0 : HRNB);
+    double* P = W + j0 + j0 * n;
+    hipLaunchKernelGGL(hr_lu_panel_kernel, dim3(1), dim3(1024), 0, s, P, n, (int)(n - j0), nb, sgn + j0);
+    const int64_t rest = n - j0 - nb;
+    if (rest > 0) {
+      HR(capi_dtrsm(h, CAPI_LEFT, CAPI_LOWER, CAPI_NOTRANS, CAPI_UNIT, nb, rest, 1.0, P, n, P + (int64_t)nb * n, n));
+      HR(capi_dgemm(h, CAPI_NOTRANS, CAPI_NOTRANS, rest, rest, nb, -1.0, P + nb, n, P + (int64_t)nb * n, n, 1.0, P + nb + (int64_t)nb * n, n));
+    }
+  }
+  // Y2 = Q(n:m, :) U^-1 straight into the output; then the top block
+  HR(capi_memset_async(h, Ui, 0, sizeof(double) * nn));
+  HR(capi_dlacpy(h, 1, n, n, W, n, Ui, n));
+  HR(capi_dtrtri(h, CAPI_UPPER, CAPI_NONUNIT, n, Ui, n));
+  if (m > n) HR(capi_dtrmm_oop(h, CAPI_RIGHT, CAPI_UPPER, CAPI_NOTRANS, CAPI_NONUNIT, m - n, n, 1.0, Ui, n, Q2 + n, m, A + n, lda));
+  hipLaunchKernelGGL(hr_assemble_kernel, dim3((unsigned)cdiv(n, 256), (unsigned)(n < 65535 ? n : 65535)), dim3(256), 0, s, A, lda, W, Rf, sgn, (int)n, tau);
+  if (hipGetLastError() != hipSuccess) return fail(CAPI_EHIP);
+#undef HR
+  *done = 1;
+  return fail(CAPI_OK);                                      // (synchronise, release the buffer)
+}
+
 }  // namespace
 
 extern "C" {
@@ -291,6 +414,12 @@ int capi_dgeqrf(capi_handle_t h, int64_t m, int64_t n, double* A, int64_t lda, d
   if (m == 0 || n == 0) return CAPI_OK;
   CAPI_REQUIRE(h, A && tau && lda >= m, "operands");
   const int64_t k = m < n ? m : n;
+  static const bool no_hr = getenv("CAPI_GEQRF_NO_RECONSTRUCT") != nullptr;
+  if (!no_hr && n >= 32 && n <= 2048 && m >= 64 * n) {
+    int done = 0;
+    RC(geqrf_tall_reconstruct(h, m, n, A, lda, tau, &done));
+    if (done) return CAPI_OK;
+  }
   qr_ws w;
   RC(qr_workspace(h, m, n, false, w));
   hipStream_t s = h->stream;

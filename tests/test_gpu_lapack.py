@@ -132,3 +132,57 @@ def test_geqrf_orgqr_properties(hip, oracle, m, n):
         ref = fac.copy(order="F")
         oracle.dorgqr(ref, dtau.cpu().numpy())
         assert np.abs(Q - ref).max() <= 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,n", [(8192, 64), (20011, 96), (30000, 192), (16384, 256)])
+def test_geqrf_tall_reconstruction_matches_oracle(hip, oracle, m, n):
+    """Tall panels (m >= 64 n) take CholeskyQR2 + Householder reconstruction (csrc/qr_f64.hip: Q - [S; 0] = Y U): the output is
+    still LAPACK's -- R, the stored reflectors and tau agree elementwise with the oracle's column-by-column dgeqr2 (1e-12),
+    and dorgqr on it gives back an orthonormal Q with Q R = A."""
+    import torch
+    from capital_amd import capi
+    rng = np.random.default_rng(m + 7 * n)
+    A = np.asfortranarray(rng.random((m, n)) - 0.5)
+    ref = A.copy(order="F")
+    tau_ref = oracle.dgeqrf(ref)
+    dA = capi.to_device(A)
+    dtau = torch.zeros(n, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    hip.call("capi_dgeqrf", m, n, capi.ptr(dA), m, capi.ptr(dtau))
+    hip.sync()
+    out = capi.to_host(dA)
+    assert np.abs(np.triu(out[:n]) - np.triu(ref[:n])).max() <= 1e-12 * np.abs(np.triu(ref[:n])).max()     # R
+    assert np.abs(np.tril(out, -1) - np.tril(ref, -1)).max() <= 1e-12                                      # reflectors (entries <= 1)
+    assert np.abs(dtau.cpu().numpy() - tau_ref).max() <= 1e-12
+    hip.call("capi_dorgqr", m, n, n, capi.ptr(dA), m, capi.ptr(dtau))
+    hip.sync()
+    Q = capi.to_host(dA)
+    assert np.abs(Q.T @ Q - np.eye(n)).max() <= 1e-13
+    assert np.abs(Q @ np.triu(out[:n]) - A).max() <= 1e-13 * n
+
+
+@pytest.mark.gpu
+def test_geqrf_tall_ill_conditioned_falls_back(hip, oracle):
+    """kappa ~ 1e12 on a tall panel: CholeskyQR2 is not safe (the first sweep's diagonal ratio says so), the Householder panels
+    run instead and the factorisation is as good as ever"""
+    import torch
+    from capital_amd import capi
+    m, n = 20000, 64
+    rng = np.random.default_rng(5)
+    A = np.asfortranarray((rng.random((m, n)) - 0.5) * np.logspace(0, -12, n)[None, :])
+    dA = capi.to_device(A)
+    dtau = torch.zeros(n, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    hip.call("capi_dgeqrf", m, n, capi.ptr(dA), m, capi.ptr(dtau))
+    hip.sync()
+    fac = capi.to_host(dA)
+    ref = A.copy(order="F")
+    tau_ref = oracle.dgeqrf(ref)
+    assert np.abs(dtau.cpu().numpy() - tau_ref).max() <= 1e-12
+    R = np.triu(fac[:n])
+    hip.call("capi_dorgqr", m, n, n, capi.ptr(dA), m, capi.ptr(dtau))
+    hip.sync()
+    Q = capi.to_host(dA)
+    assert np.abs(Q.T @ Q - np.eye(n)).max() <= 1e-13
+    assert np.abs(Q @ R - A).max() <= 1e-13 * np.abs(A).max() * n

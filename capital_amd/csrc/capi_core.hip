@@ -67,6 +67,7 @@ int capi_destroy(capi_handle_t h) {
     if (h->ws[i]) (void)hipFree(h->ws[i]);
     if (h->ws2[i]) (void)hipFree(h->ws2[i]);
     if (h->ws3[i]) (void)hipFree(h->ws3[i]);
+    if (h->ws4[i]) (void)hipFree(h->ws4[i]);
   }
   if (h->d_info) (void)hipFree(h->d_info);
   if (h->h_info) (void)hipHostFree(h->h_info);
@@ -274,3 +275,19 @@ static int ws_grow(capi_handle_t h, void** slot, size_t* cap, size_t bytes, void
 int capi_ws_get(capi_handle_t h, size_t bytes, void** p) { return h ? ws_grow(h, &h->ws[h->cur], &h->ws_bytes[h->cur], bytes, p) : CAPI_EINVAL; }
 int capi_ws2_get(capi_handle_t h, size_t bytes, void** p) { return h ? ws_grow(h, &h->ws2[h->cur], &h->ws2_bytes[h->cur], bytes, p) : CAPI_EINVAL; }
 int capi_ws3_get(capi_handle_t h, size_t bytes, void** p) { return h ? ws_grow(h, &h->ws3[h->cur], &h->ws3_bytes[h->cur], bytes, p) : CAPI_EINVAL; }
+int capi_ws4_get(capi_handle_t h, size_t bytes, void** p) { return h ? ws_grow(h, &h->ws4[h->cur], &h->ws4_bytes[h->cur], bytes, p) : CAPI_EINVAL; }
+
+// release every private workspace block of the handle (they grow on demand and are otherwise kept until capi_destroy)
+extern "C" int capi_trim_workspaces(capi_handle_t h) {
+  CAPI_REQUIRE(h, h, "null handle");
+  CAPI_HIP_CHECK(h, hipSetDevice(h->device));
+  int rc = capi_sync(h);
+  if (rc != CAPI_OK) return rc;
+  for (int i = 0; i < capi_handle_s::NSTREAMS; ++i) {
+    void** blocks[4] = {&h->ws[i], &h->ws2[i], &h->ws3[i], &h->ws4[i]};
+    size_t* sizes[4] = {&h->ws_bytes[i], &h->ws2_bytes[i], &h->ws3_bytes[i], &h->ws4_bytes[i]};
+    for (int b = 0; b < 4; ++b)
+      if (*blocks[b]) { CAPI_HIP_CHECK(h, hipFree(*blocks[b])); *blocks[b] = nullptr; *sizes[b] = 0; }
+  }
+  return CAPI_OK;
+}

@@ -27,6 +27,10 @@ struct capi_handle_s {
   // third block: clean copies of small triangular operands (tall right-TRMM); never aliases what callers keep in ws / ws2
   void* ws3[NSTREAMS] = {nullptr, nullptr, nullptr, nullptr};
   size_t ws3_bytes[NSTREAMS] = {0, 0, 0, 0};
+  // fourth block: the tall QR paths' panels (CholeskyQR2 + Householder reconstruction keeps two m x n images beside the BLAS /
+  // LAPACK calls it makes, which use ws / ws2 / ws3 themselves).  hipMalloc of tens of GiB takes hundreds of ms: kept between calls
+  void* ws4[NSTREAMS] = {nullptr, nullptr, nullptr, nullptr};
+  size_t ws4_bytes[NSTREAMS] = {0, 0, 0, 0};
   // device-side LAPACK info word (0 ok, >0 first bad pivot, 1-based) + pinned host mirror
   int* d_info = nullptr;
   int* h_info = nullptr;
@@ -74,5 +78,6 @@ enum { CAPI_ATTR_LEAF = 0, CAPI_ATTR_TRMM_TS32 = 1, CAPI_ATTR_TRMM_TS16 = 2, CAP
 int capi_ws_get(capi_handle_t h, size_t bytes, void** p);
 int capi_ws2_get(capi_handle_t h, size_t bytes, void** p);
 int capi_ws3_get(capi_handle_t h, size_t bytes, void** p);
+int capi_ws4_get(capi_handle_t h, size_t bytes, void** p);
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

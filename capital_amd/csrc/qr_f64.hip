@@ -12,7 +12,11 @@
 // dorgqr applies the block reflectors, last panel first, to [I; 0] in workspace and copies the result over A.
 // HBM-bound per column (the rest of the panel is read and written once per column); dlarfg's rescaling loop for subnormal
 // norms is omitted.
+// Tall panels (m >= 64 n, n <= 2048) do not go column by column: geqrf runs CholeskyQR2 on the MFMA tall-skinny kernels and
+// RECONSTRUCTS the LAPACK output (reflectors, R, tau) from its Q and R (geqrf_tall_reconstruct below; Householder panels as the
+// fallback when CholeskyQR2 is not safe), dorgqr applies all n reflectors as ONE block reflector (orgqr_tall_one_block).
 #include <stdlib.h>
+#include <vector>
 #include "capi_internal.h"
 
 namespace {
@@ -347,14 +351,15 @@ int geqrf_tall_reconstruct(capi_handle_t h, int64_t m, int64_t n, double* A, int
   *done = 0;
   hipStream_t s = h->stream;
   const size_t nn = (size_t)n * (size_t)n;
-  double* buf = nullptr;                                     // own allocation: the BLAS / LAPACK calls below use the handle's workspaces
+  double* buf = nullptr;                                     // the handle's QR block: the BLAS / LAPACK calls below use ws / ws2 / ws3 themselves
   {
-    hipError_t e = hipMalloc((void**)&buf, sizeof(double) * (2 * (size_t)m * (size_t)n + 8 * nn + 2 * (size_t)n + 16));
-    if (e != hipSuccess) { (void)hipGetLastError(); return CAPI_OK; }      // not enough memory beside the caller's data: slow path
+    void* pv = nullptr;
+    if (capi_ws4_get(h, sizeof(double) * (2 * (size_t)m * (size_t)n + 8 * nn + 2 * (size_t)n + 16), &pv) != CAPI_OK) return CAPI_OK;   // no room: slow path
+    buf = (double*)pv;
   }
   double *Q1 = buf, *Q2 = Q1 + (size_t)m * n, *G = Q2 + (size_t)m * n, *Gi = G + nn, *R1 = Gi + nn, *Rf = R1 + nn, *W = Rf + nn, *Ui = W + nn,
          *sgn = Ui + nn + 2 * nn, *stat = sgn + n;
-  auto fail = [&](int rc) { (void)hipStreamSynchronize(s); (void)hipFree(buf); return rc; };
+  auto fail = [&](int rc) { return rc; };
   int saved_info = 0;
 #define HR(x) do { int rc__ = (x); if (rc__ != CAPI_OK) return fail(rc__); } while (0)
   HR(capi_get_info(h, &saved_info));                         // the handle's LAPACK info word is borrowed for the two Gram factorisations
@@ -401,7 +406,67 @@ int geqrf_tall_reconstruct(capi_handle_t h, int64_t m, int64_t n, double* A, int
   if (hipGetLastError() != hipSuccess) return fail(CAPI_EHIP);
 #undef HR
   *done = 1;
-  return fail(CAPI_OK);                                      // (synchronise, release the buffer)
+  return CAPI_OK;
+}
+
+
+// ---- dorgqr on tall panels: ONE block reflector of width n --------------------------------------------------------------------
+// Q(:, 0:n) = (I - Y T Y^T)(:, 0:n) = E - Y (T Y1^T) with T^-1 = strictly-upper(Y^T Y) + diag(1 / tau)  (from T^-1 + T^-T = Y^T Y and
+// ||v_i||^2 = 2 / tau_i): a tall Gram matrix, an n x n triangular inverse and one tall triangular product -- three passes over
+// the panel on the MFMA kernels instead of n / 32 block reflectors applied one after the other.  Needs k == n and every tau_i != 0
+// (a reflector with tau = 0 is the identity and has no 1 / tau); otherwise the panel-by-panel path below runs.
+__global__ void hr_tinv_kernel(double* __restrict__ G, int n, const double* __restrict__ tau) {   // G (upper, Y^T Y) -> strictly-upper(G) + diag(1/tau), zeros below
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int j = blockIdx.y; j < n; j += gridDim.y) {
+    double v = G[i + (int64_t)j * n];
+    if (i == j) v = 1.0 / tau[i];
+    if (i > j) v = 0.0;
+    G[i + (int64_t)j * n] = v;
+  }
+}
+__global__ void hr_transpose_top_kernel(const double* __restrict__ Y, int64_t ldy, int n, double* __restrict__ Yt) {   // Yt = Y(0:n, 0:n)^T
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int j = blockIdx.y; j < n; j += gridDim.y) Yt[i + (int64_t)j * n] = Y[j + (int64_t)i * ldy];
+}
+__global__ void hr_add_identity_kernel(double* __restrict__ A, int64_t lda, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) A[i + (int64_t)i * lda] += 1.0;
+}
+
+int orgqr_tall_one_block(capi_handle_t h, int64_t m, int64_t n, double* A, int64_t lda, const double* tau, int* done) {
+  *done = 0;
+  hipStream_t s = h->stream;
+  const size_t nn = (size_t)n * (size_t)n;
+  {
+    std::vector<double> ht((size_t)n);
+    int rc = capi_memcpy_d2h(h, ht.data(), tau, sizeof(double) * (size_t)n);
+    if (rc != CAPI_OK) return rc;
+    for (double t : ht) if (t == 0.0) return CAPI_OK;
+  }
+  double* buf = nullptr;
+  {
+    void* pv = nullptr;
+    if (capi_ws4_get(h, sizeof(double) * ((size_t)m * (size_t)n + 4 * nn), &pv) != CAPI_OK) return CAPI_OK;
+    buf = (double*)pv;
+  }
+  double *Y = buf, *G = Y + (size_t)m * n, *Yt = G + nn, *M = Yt + nn;
+  auto fin = [&](int rc) { return rc; };
+#define OQ(x) do { int rc__ = (x); if (rc__ != CAPI_OK) return fin(rc__); } while (0)
+  const dim3 gnn((unsigned)cdiv(n, 256), (unsigned)(n < 65535 ? n : 65535));
+  hipLaunchKernelGGL(form_v_kernel, dim3((unsigned)cdiv(m, 256), (unsigned)(n < 65535 ? n : 65535)), dim3(256), 0, s, A, lda, m, (int)n, Y);
+  OQ(capi_dsyrk(h, CAPI_UPPER, CAPI_TRANS, n, m, 1.0, Y, m, 0.0, G, n));
+  hipLaunchKernelGGL(hr_tinv_kernel, gnn, dim3(256), 0, s, G, (int)n, tau);
+  OQ(capi_dtrtri(h, CAPI_UPPER, CAPI_NONUNIT, n, G, n));                                              // G = T
+  hipLaunchKernelGGL(hr_transpose_top_kernel, gnn, dim3(256), 0, s, Y, m, (int)n, Yt);
+  OQ(capi_dtrmm_oop(h, CAPI_LEFT, CAPI_UPPER, CAPI_NOTRANS, CAPI_NONUNIT, n, n, 1.0, G, n, Yt, n, M, n));  // M = T Y1^T (upper)
+  OQ(capi_dtrmm_oop(h, CAPI_RIGHT, CAPI_UPPER, CAPI_NOTRANS, CAPI_NONUNIT, m, n, -1.0, M, n, Y, m, A, lda));
+  hipLaunchKernelGGL(hr_add_identity_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, A, lda, (int)n);
+  if (hipGetLastError() != hipSuccess) return fin(CAPI_EHIP);
+#undef OQ
+  *done = 1;
+  return fin(CAPI_OK);
 }
 
 }  // namespace
@@ -463,6 +528,12 @@ int capi_dorgqr(capi_handle_t h, int64_t m, int64_t n, int64_t k, double* A, int
   CAPI_REQUIRE(h, m >= 0 && n >= 0 && n <= m && k >= 0 && k <= n && m < (1LL << 31), "dims (m >= n >= k >= 0)");
   if (m == 0 || n == 0) return CAPI_OK;
   CAPI_REQUIRE(h, A && lda >= m && (tau || k == 0), "operands");
+  static const bool no_hr = getenv("CAPI_GEQRF_NO_RECONSTRUCT") != nullptr;
+  if (!no_hr && k == n && n >= 32 && n <= 2048 && m >= 64 * n) {
+    int done = 0;
+    RC(orgqr_tall_one_block(h, m, n, A, lda, tau, &done));
+    if (done) return CAPI_OK;
+  }
   qr_ws w;
   RC(qr_workspace(h, m, n, true, w));
   hipStream_t s = h->stream;

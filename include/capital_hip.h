@@ -58,6 +58,8 @@ int  capi_memcpy_d2d_async(capi_handle_t h, void* dst, const void* src, size_t b
 int  capi_sync(capi_handle_t h);
 /* grow the handle's private workspace (used by in-place trmm, split-K slabs, potrf) ahead of time */
 int  capi_reserve_workspace(capi_handle_t h, size_t bytes);
+/* release every private workspace block of the handle (synchronises); they are re-created on demand */
+int  capi_trim_workspaces(capi_handle_t h);
 
 /* ---- BLAS layer: replaces blas::engine::_gemm/_trmm/_syrk (src/blas/interface.h:58-66,
  *      src/blas/interface.hpp:43-97 -> cblas_dgemm/dtrmm/dsyrk) ---- */

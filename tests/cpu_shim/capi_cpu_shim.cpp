@@ -273,6 +273,7 @@ int capi_scatter(capi_comm_t c, const double* send, double* recv, int64_t count,
   return 0;
 }
 int capi_comm_query(capi_comm_t c, int* r, int* s) { if (!c) return CAPI_EINVAL; *r = c->me; *s = (int)c->ranks.size(); return 0; }
+int capi_trim_workspaces(capi_handle_t) { return 0; }
 int capi_range_push(const char*) { return 0; }
 int capi_range_pop(void) { return 0; }
 int capi_sendrecv_replace(capi_comm_t c, double* buf, int64_t count, int peer, double* staging) {

@@ -198,6 +198,42 @@ def test_tall_skinny_gram_and_right_trmm(m, n, pad):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,pad,uplo,trans,alpha,beta", [(512, 0, 1, 0, 1.0, 0.0), (768, 2, 1, 0, -0.5, 0.0), (1024, 0, 1, 0, 1.0, 0.0), (1024, 3, 0, 1, 2.0, 0.0),
+                                                          (1000, 0, 1, 0, 1.0, 0.0), (1024, 0, 0, 0, 1.0, 0.0), (512, 2, 1, 1, 1.0, 0.0), (768, 0, 1, 0, 1.0, 0.75)])
+def test_tall_products_wider_than_256(n, pad, uplo, trans, alpha, beta):
+    """Tall-skinny products at the widths of BASELINE config 5 (n = 1024) and around it, m just above 64 n so that the tall paths
+    engage: Gram matrix by 256-blocks (diagonal blocks on the full-width kernel, off-diagonal blocks as split-K products), right
+    TRMM with a clean copy of T, one launch per 256-column block when op(T) is upper; ragged m, padded leading dimension, the
+    widths that do NOT divide by 256 (generic path), lower / transposed T, alpha, and beta on the Gram matrix -- all against torch fp64."""
+    import torch
+    from capital_amd import capi
+    h = capi.Handle(0)
+    torch.manual_seed(n + pad + 10 * uplo + trans)
+    m = 64 * n + 77
+    ld = m + pad
+    A = torch.rand((n, ld), dtype=torch.float64, device="cuda") - 0.5           # column-major m x n, leading dimension ld
+    Q = torch.zeros((n, ld), dtype=torch.float64, device="cuda")
+    Tfull = torch.rand((n, n), dtype=torch.float64, device="cuda") - 0.5        # logical matrix; only its `uplo` triangle may be read
+    Tcm = Tfull.T.contiguous()                                                   # column-major storage
+    Tlog = torch.triu(Tfull) if uplo == 1 else torch.tril(Tfull)
+    opT = Tlog.T if trans else Tlog
+    G0 = torch.rand((n, n), dtype=torch.float64, device="cuda")
+    G = G0.clone()
+    torch.cuda.synchronize()
+    h.call("capi_dsyrk", 1, 1, n, m, alpha, capi.ptr(A), ld, beta, capi.ptr(G), n)
+    h.call("capi_dtrmm_oop", 1, uplo, trans, 0, m, n, alpha, capi.ptr(Tcm), n, capi.ptr(A), ld, capi.ptr(Q), ld)
+    h.sync()
+    Am = A[:, :m].T
+    Gref = alpha * torch.triu(Am.T @ Am) + beta * torch.triu(G0.T)
+    assert (torch.triu(G.T) - Gref).abs().max().item() <= 1e-13 * Gref.abs().max().item()
+    assert torch.equal(torch.tril(G.T, -1), torch.tril(G0.T, -1))                # the other triangle of C is neither read nor written
+    Qref = alpha * (Am @ opT)
+    assert (Q[:, :m].T - Qref).abs().max().item() <= 1e-13 * Qref.abs().max().item()
+    assert torch.count_nonzero(Q[:, m:]).item() == 0
+    h.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,k", [(5000, 300), (6016, 200)])
 def test_partial_last_round_is_recut_into_64_tiles(n, k):
     """Orders whose 128-tiling leaves a partial last round (1600 = 3 x 512 + 64 tiles for gemm 5000, 1128 = 2 x 512 + 104

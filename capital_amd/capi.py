@@ -46,6 +46,7 @@ _SIGS = {
     "capi_cyclic_to_block": [_vp, _vp, _i64, _i64, _i64],
     "capi_block_to_cyclic_tri": [_vp, _vp, _i64, _i64],
     "capi_cyclic_to_block_tri": [_vp, _vp, _i64, _i64],
+    "capi_cyclic_to_local": [_vp, _vp, _i64, _i64, _i64, _i64],
     "capi_distribute_symmetric": [_vp] + [_i64] * 9 + [_int],
     "capi_distribute_random": [_vp] + [_i64] * 9,
     "capi_distribute_identity": [_vp] + [_i64] * 8 + [_dbl],

@@ -134,6 +134,26 @@ __global__ void block_cyclic_tri_kernel(int to_cyclic, double* __restrict__ bloc
   }
 }
 
+// util::cyclic_to_local (util.hpp:131-164): this rank's element-cyclic piece (slice rank sr: row offset sr / d, column offset sr % d)
+// of the aggregated factor T and of its inverse TI, each bc x bc, moved into the leading L x L corner (leading dimension stays bc),
+// entries below the GLOBAL diagonal zeroed.  The reference does it in place, front to back; in parallel the piece goes through a
+// compact scratch image first (pass 0: gather, pass 1: scatter back).
+__global__ void cyclic_to_local_kernel(int pass, double* __restrict__ T, double* __restrict__ TI, double* __restrict__ tmp, int64_t L, int64_t bc,
+                                       int64_t d, int64_t ro, int64_t co) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= L) return;
+  for (int64_t i = blockIdx.y; i < L; i += gridDim.y) {
+    const int64_t rc = i * d + co, rr = j * d + ro;
+    if (pass == 0) {
+      tmp[i * L + j] = rc >= rr ? T[rc * bc + rr] : 0.0;
+      tmp[L * L + i * L + j] = rc >= rr ? TI[rc * bc + rr] : 0.0;
+    } else {
+      T[i * bc + j] = tmp[i * L + j];
+      TI[i * bc + j] = tmp[L * L + i * L + j];
+    }
+  }
+}
+
 // ---- POSIX drand48 in closed form (the reference calls srand48/drand48: structure.hpp:68-129) ----
 constexpr uint64_t LCG_A = 0x5DEECE66DULL, LCG_C = 0xBULL, LCG_MASK = (1ULL << 48) - 1;
 
@@ -338,6 +358,18 @@ int capi_block_to_cyclic_tri(capi_handle_t h, const double* blocked, double* cyc
 int capi_cyclic_to_block_tri(capi_handle_t h, double* blocked, const double* cyclic, int64_t rl, int64_t d) {
   CAPI_REQUIRE(h, h && blocked && cyclic && rl > 0 && d > 0, "args");
   hipLaunchKernelGGL(block_cyclic_tri_kernel, grid2(rl * d, rl * d), dim3(256), 0, h->stream, 0, blocked, (double*)cyclic, rl, d);
+  CAPI_HIP_CHECK(h, hipGetLastError());
+  return CAPI_OK;
+}
+
+int capi_cyclic_to_local(capi_handle_t h, double* T, double* TI, int64_t local_dim, int64_t bc_dim, int64_t d, int64_t slice_rank) {
+  CAPI_REQUIRE(h, h && T && TI && local_dim > 0 && d > 0 && bc_dim >= local_dim * d && slice_rank >= 0 && slice_rank < d * d, "args");
+  void* w;
+  int rc = capi_ws2_get(h, sizeof(double) * 2 * (size_t)local_dim * (size_t)local_dim, &w);
+  if (rc != CAPI_OK) return rc;
+  for (int pass = 0; pass < 2; ++pass)
+    hipLaunchKernelGGL(cyclic_to_local_kernel, grid2(local_dim, local_dim), dim3(256), 0, h->stream, pass, T, TI, (double*)w, local_dim, bc_dim, d,
+                       slice_rank / d, slice_rank % d);
   CAPI_HIP_CHECK(h, hipGetLastError());
   return CAPI_OK;
 }

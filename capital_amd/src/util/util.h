@@ -45,6 +45,19 @@ public:
   static void cyclic_to_block_rect(double* blocked, const double* cyclic, int64_t rows_local, int64_t cols_local, int64_t sliceDim) {
     CAPITAL_CHECK(capi_cyclic_to_block(capital::handle(), blocked, cyclic, rows_local, cols_local, sliceDim));
   }
+  // packed upper-triangular pieces (util.hpp:57-102,167-201); num_elems = sliceDim^2 * rows_local (rows_local + 1) / 2 as in the reference
+  static void block_to_cyclic_triangle(const double* blocked, double* cyclic, int64_t num_elems, int64_t rows_local, int64_t cols_local, int64_t sliceDim) {
+    if (rows_local != cols_local || num_elems != sliceDim * sliceDim * (rows_local * (rows_local + 1) / 2)) throw std::invalid_argument("block_to_cyclic_triangle: square packed pieces expected");
+    CAPITAL_CHECK(capi_block_to_cyclic_tri(capital::handle(), blocked, cyclic, rows_local, sliceDim));
+  }
+  static void cyclic_to_block_triangle(double* blocked, const double* cyclic, int64_t num_elems, int64_t rows_local, int64_t cols_local, int64_t sliceDim) {
+    if (rows_local != cols_local || num_elems != sliceDim * sliceDim * (rows_local * (rows_local + 1) / 2)) throw std::invalid_argument("cyclic_to_block_triangle: square packed pieces expected");
+    CAPITAL_CHECK(capi_cyclic_to_block_tri(capital::handle(), blocked, cyclic, rows_local, sliceDim));
+  }
+  // util.hpp:131-164
+  static void cyclic_to_local(double* storeT, double* storeTI, int64_t localDimension, int64_t bcDimension, int64_t sliceDim, int64_t sliceRank) {
+    CAPITAL_CHECK(capi_cyclic_to_local(capital::handle(), storeT, storeTI, localDimension, bcDimension, sliceDim, sliceRank));
+  }
 
   // util.hpp:249-264
   static int64_t get_next_power2(int64_t v) {

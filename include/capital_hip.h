@@ -138,6 +138,9 @@ int capi_cyclic_to_block(capi_handle_t h, double* blocked, const double* cyclic,
  * cyclic_to_block_triangle, util.hpp:57-102,167-201: the Serialize policy's base-case messages, policy.h:176,322-377) */
 int capi_block_to_cyclic_tri(capi_handle_t h, const double* blocked_packed, double* cyclic, int64_t rows_local, int64_t d);
 int capi_cyclic_to_block_tri(capi_handle_t h, double* blocked_packed, const double* cyclic, int64_t rows_local, int64_t d);
+/* util::cyclic_to_local (util.hpp:131-164): slice rank `slice_rank`'s element-cyclic piece of the aggregated factor T and of its
+ * inverse TI (bc_dim x bc_dim each) into their leading local_dim x local_dim corners (ld stays bc_dim), zero below the global diagonal */
+int capi_cyclic_to_local(capi_handle_t h, double* T, double* TI, int64_t local_dim, int64_t bc_dim, int64_t d, int64_t slice_rank);
 
 /* ---- generators: replaces rect::_distribute_* (src/matrix/structure.hpp:36-129), bit-identical output ---- */
 int capi_distribute_symmetric(capi_handle_t h, double* data, int64_t dimX, int64_t dimY, int64_t gdimX, int64_t gdimY,

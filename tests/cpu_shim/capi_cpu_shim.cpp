@@ -172,6 +172,10 @@ int capi_cyclic_to_block_tri(capi_handle_t, double* blocked, const double* cycli
   orc_cyclic_to_block_triangle(blocked, cyclic, d * d * (rl * (rl + 1) / 2), rl, rl, d);
   return 0;
 }
+int capi_cyclic_to_local(capi_handle_t, double* T, double* TI, int64_t L, int64_t bc, int64_t d, int64_t sr) {
+  orc_cyclic_to_local(T, TI, L, bc, d, sr);
+  return 0;
+}
 int capi_distribute_symmetric(capi_handle_t, double* data, int64_t dimX, int64_t dimY, int64_t gX, int64_t gY, int64_t px, int64_t py,
                               int64_t PX, int64_t PY, int64_t key, int dd) {
   orc_distribute_symmetric(data, dimX, dimY, gX, gY, px, py, PX, PY, key, dd);

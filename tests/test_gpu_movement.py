@@ -187,3 +187,26 @@ def test_block_cyclic_triangle(hip, oracle, rl, d):
     np.testing.assert_array_equal(got, back)
     changed = np.nonzero(got != blocked)[0]
     assert len(changed) == rl * (d * (d - 1) // 2) and np.all(got[changed] == 0.0)   # local diagonals of the pieces with y > x
+
+
+@pytest.mark.parametrize("L,d", [(8, 2), (5, 3), (33, 2), (16, 1)])
+def test_cyclic_to_local(hip, oracle, L, d):
+    """util::cyclic_to_local (util.hpp:131-164) for every slice rank: bit-exact against the oracle's front-to-back restatement"""
+    import ctypes as C
+    import torch
+    from capital_amd import capi
+    bc = L * d
+    rng = np.random.default_rng(L + 13 * d)
+    dp = C.POINTER(C.c_double)
+    for sr in range(d * d):
+        T, TI = rng.uniform(size=bc * bc), rng.uniform(size=bc * bc)
+        rT, rTI = T.copy(), TI.copy()
+        oracle.lib().orc_cyclic_to_local.argtypes = [dp, dp] + [C.c_int64] * 4
+        oracle.lib().orc_cyclic_to_local(rT.ctypes.data_as(dp), rTI.ctypes.data_as(dp), L, bc, d, sr)
+        dT, dTI = torch.from_numpy(T).cuda(), torch.from_numpy(TI).cuda()
+        torch.cuda.synchronize()
+        hip.call("capi_cyclic_to_local", capi.ptr(dT), capi.ptr(dTI), L, bc, d, sr)
+        hip.sync()
+        got, goti = dT.cpu().numpy().reshape(bc, bc), dTI.cpu().numpy().reshape(bc, bc)
+        np.testing.assert_array_equal(got[:L, :L], rT.reshape(bc, bc)[:L, :L])           # the leading corner (column index first)
+        np.testing.assert_array_equal(goti[:L, :L], rTI.reshape(bc, bc)[:L, :L])

@@ -92,6 +92,7 @@ struct GemmArgs {
   int tri_koff;       // tri_dense, right side, upper: this launch holds columns [tri_koff, tri_koff + N) of op(T): column tile tj's k-range
                       // ends at tri_koff + (tj + 1) TS.  Tiles are then dealt like a plain product's (tri_block)
   int tri_block;
+  int pid_base;       // this launch covers pids [pid_base, pid_base + gridDim.x) of the tile enumeration (launch in resident rounds)
 };
 
 // ---- global -> registers: this thread's 4 x 16 bytes of a 128 x 16 operand panel -----------------
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel
   // XCD-aware re-deal: consecutive pids share an XCD (dispatcher deals blockIdx round-robin over 8 XCDs)
   const int nblk = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, qq = nblk >> 3, rr = nblk & 7;
-  const int pid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const int pid = p.pid_base + (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
   int z = pid / p.ntiles;
   int ti, tj;
   if (p.tri_side >= 0 && p.splitk == 1 && !p.tri_block) { z = 0; trmm_tile_of(p, bid, ti, tj); }
@@ -1520,8 +1521,12 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
   // A 128-tiling fills the chip in rounds of 2 x CUs workgroups; the last round is usually partial and its lone
   // workgroups run at ~0.6 of the paired rate (8256 tiles = 16 rounds + 64: those 64 cost almost another round).  The
   // tail is re-cut into 64-tiles (4x the workgroups, a quarter of the length) and launched right behind the full rounds.
+  static const int rounds_mode = getenv("CAPI_ROUNDS") ? atoi(getenv("CAPI_ROUNDS")) : 0;
+  const int64_t per_round = 2 * (int64_t)(h->cu_of[h->cur] ? h->cu_of[h->cur] : h->num_cu);
+  const bool use_rounds = rounds_mode > 0 && p.ts == 128 && p.splitk == 1 && !tri && p.out_uplo < 0 && per_round == 512 && p.batch <= 1 &&
+                          (int64_t)p.ntiles >= 2 * per_round;      // (see "Resident rounds" below)
   int tail128 = 0;
-  if (p.ts == 128 && p.splitk == 1 && !tri && !getenv("CAPI_NO_TAIL")) {
+  if (p.ts == 128 && p.splitk == 1 && !tri && !use_rounds && !getenv("CAPI_NO_TAIL")) {
     const int per_round = 2 * (h->cu_of[h->cur] ? h->cu_of[h->cur] : h->num_cu);
     const int rem = p.ntiles % per_round;
     if (p.ntiles >= 2 * per_round && rem > 0 && rem <= (3 * per_round) / 4) tail128 = rem;
@@ -1533,8 +1538,10 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
   const size_t lds_bytes = sizeof(double) * 2 * (p.ts == 128 ? tile_cfg<128>::STAGE_LDS : tile_cfg<64>::STAGE_LDS);
   const int64_t nblk = (int64_t)p.ntiles * p.splitk;
   CAPI_REQUIRE(h, nblk < (int64_t)1 << 31, "too many tiles");
-  capi_handle_s::prof_rec* rec = nullptr;
-  if (h->prof_on) {
+  // HIP events around EVERY launch of the tile kernel (capi_prof_*): one record per launch, its share of the algorithmic flops
+  auto prof_open = [&](double share, capi_handle_s::prof_rec*& rec) -> int {
+    rec = nullptr;
+    if (!h->prof_on) return CAPI_OK;
     if (h->prof_n == h->prof_cap) {
       const int ncap = h->prof_cap ? h->prof_cap * 2 : 1024;
       auto* np_ = (capi_handle_s::prof_rec*)realloc(h->prof, sizeof(capi_handle_s::prof_rec) * ncap);
@@ -1545,16 +1552,45 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
     }
     rec = &h->prof[h->prof_n++];
     if (!rec->e0) { CAPI_HIP_CHECK(h, hipEventCreate(&rec->e0)); CAPI_HIP_CHECK(h, hipEventCreate(&rec->e1)); }
-    // algorithmic flops of this launch: gemm 2MNK, triangular output N(N+1)K, trmm M^2 N / M N^2
+    // algorithmic flops of the whole product: gemm 2MNK, triangular output N(N+1)K, trmm M^2 N / M N^2
     rec->flops = p.out_uplo >= 0 ? (double)p.N * ((double)p.N + 1.0) * (double)p.K
                  : (p.tri_side >= 0 ? (double)p.M * (double)p.N * (double)p.K : 2.0 * (double)p.M * (double)p.N * (double)p.K);
-    rec->flops *= (double)p.ntiles / (double)ntiles_all;           // (the tail launch below is not part of this record)
+    rec->flops *= share;
     rec->variant = (ak ? 2 : 0) + (bkc ? 1 : 0) + (p.ts == 128 ? 0 : 4);
     CAPI_HIP_CHECK(h, hipEventRecord(rec->e0, s));
+    return CAPI_OK;
+  };
+  // Resident rounds (plain products).  A launch with more tiles than the chip holds (2 per CU) refills slots one by one as tiles
+  // finish: within a few tile lengths the starts are smeared and tiles that share an operand panel are no longer within the ~2
+  // iterations an XCD's 4 MiB L2 can bridge (its 64 resident tiles pull 2 MiB of panels through it per iteration).  One launch per
+  // round restarts every XCD's 64 tiles together, as an 8 x 8 block of the tile grid (tile_of_dims' bands): 16 panels serve 64
+  // tiles.  dgemm 16384^3: FETCH 139 -> 76 GB (the 8-way ideal is 69), time unchanged (118.7 vs 119.0 ms): the tiles of a plain
+  // product do equal work, so the round boundary costs nothing measurable.  Triangular outputs were tried the same way (8 x 8
+  // super-blocks of the triangle, 8 per round): FETCH of the n = 32768 step 310 -> 263 GB only, dsyrk 16384 62.6 -> 64.2 ms,
+  // step 237 -> 242 ms (partial rounds, diagonal super-blocks with 36 live tiles): not kept.  TRMM tiles have unequal k-ranges
+  // and keep the longest-first free-running order.  OFF by default (CAPI_ROUNDS=1 turns it on): inside cholinv the plain products
+  // are the lookahead's rectangles only -- the step's fabric traffic falls by 5 % (3625 -> 3437 GB at n = 65536), its time does
+  // not change, and the per-launch durations the roofline is computed from stretch, because the round launches of a low-priority
+  // bulk stream queue behind the chain's kernels at every boundary (0.876 -> 0.825 on the same box).
+  if (use_rounds) {
+    for (int64_t base = 0; base < nblk; base += per_round) {
+      GemmArgs q = p;
+      q.pid_base = (int)base;
+      const int64_t cnt = nblk - base < per_round ? nblk - base : per_round;
+      capi_handle_s::prof_rec* rec;
+      int rc = prof_open((double)cnt / (double)ntiles_all, rec);
+      if (rc != CAPI_OK) return rc;
+      hipLaunchKernelGGL(k, dim3((unsigned)cnt), dim3(NTHREADS), lds_bytes, s, q);
+      if (rec) CAPI_HIP_CHECK(h, hipEventRecord(rec->e1, s));
+    }
+  } else {
+    capi_handle_s::prof_rec* rec;
+    int rc = prof_open((double)p.ntiles / (double)ntiles_all, rec);              // (the tail launch below is not part of this record)
+    if (rc != CAPI_OK) return rc;
+    hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(NTHREADS), lds_bytes, s, p);
+    if (rec) CAPI_HIP_CHECK(h, hipEventRecord(rec->e1, s));
   }
-  hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(NTHREADS), lds_bytes, s, p);
   CAPI_HIP_CHECK(h, hipGetLastError());
-  if (rec) CAPI_HIP_CHECK(h, hipEventRecord(rec->e1, s));
   if (tail128 > 0) {
     GemmArgs q = p;
     q.ts = 64;

@@ -199,7 +199,8 @@ def test_tall_skinny_gram_and_right_trmm(m, n, pad):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,pad,uplo,trans,alpha,beta", [(512, 0, 1, 0, 1.0, 0.0), (768, 2, 1, 0, -0.5, 0.0), (1024, 0, 1, 0, 1.0, 0.0), (1024, 3, 0, 1, 2.0, 0.0),
-                                                          (1000, 0, 1, 0, 1.0, 0.0), (1024, 0, 0, 0, 1.0, 0.0), (512, 2, 1, 1, 1.0, 0.0), (768, 0, 1, 0, 1.0, 0.75)])
+                                                          (1000, 0, 1, 0, 1.0, 0.0), (1024, 0, 0, 0, 1.0, 0.0), (512, 2, 1, 1, 1.0, 0.0), (768, 0, 1, 0, 1.0, 0.75),
+                                                          (2048, 0, 1, 0, 1.0, 0.0)])
 def test_tall_products_wider_than_256(n, pad, uplo, trans, alpha, beta):
     """Tall-skinny products at the widths of BASELINE config 5 (n = 1024) and around it, m just above 64 n so that the tall paths
     engage: Gram matrix by 256-blocks (diagonal blocks on the full-width kernel, off-diagonal blocks as split-K products), right

@@ -231,6 +231,13 @@ def test_tall_products_wider_than_256(n, pad, uplo, trans, alpha, beta):
     Qref = alpha * (Am @ opT)
     assert (Q[:, :m].T - Qref).abs().max().item() <= 1e-13 * Qref.abs().max().item()
     assert torch.count_nonzero(Q[:, m:]).item() == 0
+    if n <= 768:                                          # the in-place form (cblas_dtrmm's own) on the same operands: bit-identical result
+        B = A.clone()
+        torch.cuda.synchronize()
+        h.call("capi_dtrmm", 1, uplo, trans, 0, m, n, alpha, capi.ptr(Tcm), n, capi.ptr(B), ld)
+        h.sync()
+        assert torch.equal(B[:, :m], Q[:, :m])
+        assert torch.equal(B[:, m:], A[:, m:])
     h.close()
 
 

@@ -617,7 +617,7 @@ __global__ void transpose_tri_kernel(const double* __restrict__ src, int64_t lds
   }
 }
 
-const int TRSM_LEAF = 256;
+static const int TRSM_LEAF = getenv("CAPI_TRSM_LEAF") ? atoi(getenv("CAPI_TRSM_LEAF")) : 256;   // diagonal blocks of this order are inverted (diagnostic override)
 
 // E = op(T).  Left: E X = B;  Right: X E = B.  In place on B.
 int trsm_rec(capi_handle_t h, int side, int uplo, int trans, int diag, int64_t m, int64_t n, const double* T, int64_t ldt,

@@ -38,7 +38,7 @@ struct capi_handle_s {
   int num_cu = 256;
   // per-launch HIP-event bracketing of the MFMA tile kernel (capi_prof_*): events live in a pool, results are summed on collect
   bool prof_on = false;
-  struct prof_rec { hipEvent_t e0, e1; double flops; int variant; };
+  struct prof_rec { hipEvent_t e0, e1; double flops; int variant; int m, n, k, kind; };   // kind: 0 plain, 1 triangular output, 2 TRMM
   prof_rec* prof = nullptr;
   int prof_n = 0, prof_cap = 0;
   // kernels whose dynamic-LDS limit has been raised on THIS handle's device (hipFuncSetAttribute is per device; a
@@ -48,7 +48,7 @@ struct capi_handle_s {
 };
 
 enum { CAPI_ATTR_LEAF = 0, CAPI_ATTR_TRMM_TS32 = 1, CAPI_ATTR_TRMM_TS16 = 2, CAPI_ATTR_GRAM_TS = 3, CAPI_ATTR_SMALL0 = 4 /* ..7 */,
-       CAPI_ATTR_GRAM_WIDE = 8, CAPI_ATTR_TRMM_WIDE = 9 };
+       CAPI_ATTR_GRAM_WIDE = 8, CAPI_ATTR_TRMM_WIDE = 9, CAPI_ATTR_PAIR0 = 10 /* ..13 */ };
 #define CAPI_RAISE_LDS_LIMIT(h, bit, fn, bytes)                                                                    \
   do {                                                                                                             \
     if (!((h)->lds_attr_done & (1u << (bit)))) {                                                                   \

@@ -93,6 +93,7 @@ struct GemmArgs {
                       // ends at tri_koff + (tj + 1) TS.  Tiles are then dealt like a plain product's (tri_block)
   int tri_block;
   int pid_base;       // this launch covers pids [pid_base, pid_base + gridDim.x) of the tile enumeration (launch in resident rounds)
+  int order;          // bit 0: a triangular output's tiles run in bands of 8 tile rows (tile_of_dims)
 };
 
 // ---- global -> registers: this thread's 4 x 16 bytes of a 128 x 16 operand panel -----------------
@@ -233,8 +234,32 @@ __device__ __forceinline__ void mfma_step(d4_t (&acc)[SUB][SUB], const d2_t (&af
   }
 }
 
-__device__ __forceinline__ void tile_of_dims(int out_uplo, int nm, int nn, int t, int& ti, int& tj) {
-  if (out_uplo < 0) {
+__device__ __forceinline__ void tile_of_dims(int out_uplo, int nm, int nn, int t, int& ti, int& tj, int order = 0) {
+  if (out_uplo >= 0 && (order & 1)) {
+    // pairs (lo <= hi) in bands of GROUP_M values of lo: the band's diagonal triangle first, then hi outwards with the band's
+    // GROUP_M values of lo under each -- an XCD's 64 resident tiles then form an 8 x 8 block of the triangle (16 panels
+    // instead of 65 behind 64 tiles), as a plain product's do
+    int first = 0, gsz = GROUP_M;
+    for (;; first += GROUP_M) {
+      gsz = min(nn - first, GROUP_M);
+      const int cnt = gsz * (gsz + 1) / 2 + gsz * (nn - first - gsz);
+      if (t < cnt || first + GROUP_M >= nn) break;
+      t -= cnt;
+    }
+    const int ntri = gsz * (gsz + 1) / 2;
+    int lo, hi;
+    if (t < ntri) {
+      hi = 0;
+      while ((hi + 1) * (hi + 2) / 2 <= t) ++hi;
+      lo = first + t - hi * (hi + 1) / 2;
+      hi += first;
+    } else {
+      t -= ntri;
+      hi = first + gsz + t / gsz;
+      lo = first + t % gsz;
+    }
+    if (out_uplo == CAPI_UPPER) { ti = lo; tj = hi; } else { ti = hi; tj = lo; }
+  } else if (out_uplo < 0) {
     // bands of GROUP_M tile-rows (all tile-columns) are dealt to XCDs in order
     const int in_group = GROUP_M * nn;
     const int group = t / in_group;
@@ -257,11 +282,11 @@ __device__ __forceinline__ void tile_of(const GemmArgs& p, int t, int& ti, int& 
   if (p.tail_base > 0) {
     // the last, partially filled round of a 128-tiling is re-cut into 64-tiles: quarter t & 3 of 128-tile tail_base + t / 4
     int ti128, tj128;
-    tile_of_dims(p.out_uplo, p.tail_tm, p.tail_tn, p.tail_base + (t >> 2), ti128, tj128);
+    tile_of_dims(p.out_uplo, p.tail_tm, p.tail_tn, p.tail_base + (t >> 2), ti128, tj128, p.order);
     ti = 2 * ti128 + (t & 1);
     tj = 2 * tj128 + ((t >> 1) & 1);
   } else {
-    tile_of_dims(p.out_uplo, p.tiles_m, p.tiles_n, t, ti, tj);
+    tile_of_dims(p.out_uplo, p.tiles_m, p.tiles_n, t, ti, tj, p.order);
   }
 }
 
@@ -563,6 +588,203 @@ __global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel
         for (int reg = 0; reg < 4; ++reg) {
           const int j = j0 + wn * (TS / 2) + b * 16 + g + 4 * reg;
           if (element_ok(i, j)) p.C[i + (int64_t)j * p.ldc] = p.alpha * acc[a][b][reg] + p.beta * old[b][reg];
+        }
+    }
+  }
+}
+
+// ---- TRMM in tile PAIRS ------------------------------------------------------------------------------------------
+// The tiles of a triangular product have k-ranges of 1 .. ntri panels-of-128, so (dgemm_tile_kernel, trmm_tile_of) they are
+// dealt longest first and run free: the tiles resident on an XCD are at unrelated depths of k, every one streams its own
+// panel of the dense operand (measured at order 32768: 2 x FETCH_SIZE = 1.19 TB, 1.9-fold sharing), and below order ~8192
+// the unequal lengths no longer pack into the 512 slots (order 4096: 50 TFLOP/s).
+// Here one workgroup computes tile b AND tile ntri - 1 - b of the same panel of the dense operand: every workgroup does
+// (ntri + 1) x 128 of k, the launch is a plain product's (bands of 8 pair-rows x 8 columns per XCD, equal work).  All k-ranges of a triangular operand share one end (the anchor: 0 or K).  Phase 0 walks the SHORT tile away
+// from the anchor, phase 1 walks the LONG tile back towards it: a workgroup that entered phase 1 after s panels is at
+// depth Ktot - s exactly when its neighbours -- still in phase 0 or already in phase 1 -- are, whatever their own
+// lengths.  The 64 workgroups of an XCD therefore walk k in step through both phases and share 8 + 8 panels per step.
+// Requirements (launch_gemm): M, N, K multiples of 128, 16-byte aligned operands, beta == 0, an even number of tile rows.
+template <bool AK, bool BKC>
+__global__ __launch_bounds__(NTHREADS, 2) void dtrmm_pair_kernel(const GemmArgs p) {
+  constexpr int TS = 128, BM = TS, BN = TS, SUB = tile_cfg<TS>::SUB, NQ = tile_cfg<TS>::NQ;
+  constexpr bool LOADS_IN_SHADOW = LOADS_IN_SHADOW_ON && ((AK && BKC) || TRANSPOSE_STAGE);
+  constexpr int NW = NQ * ((AK || !TRANSPOSE_STAGE ? 1 : 2) + (BKC || !TRANSPOSE_STAGE ? 1 : 2));
+  constexpr int TILE_LDS = tile_cfg<TS>::TILE_LDS, STAGE_LDS = tile_cfg<TS>::STAGE_LDS;
+  constexpr int kstep = BK;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int wm = wave & 1, wn = wave >> 1;
+
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, qq = nblk >> 3, rr = nblk & 7;
+  const int pid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const bool left = p.tri_side == CAPI_LEFT;
+  const int ntri = left ? p.tiles_m : p.tiles_n, nfree = left ? p.tiles_n : p.tiles_m, npair = ntri >> 1;
+  int pb, fr;
+  if (left) tile_of_dims(-1, npair, nfree, pid, pb, fr); else tile_of_dims(-1, nfree, npair, pid, fr, pb);
+  const bool anchor0 = left ? !p.tri_eff_upper : (p.tri_eff_upper != 0);      // k-ranges [0, (b + 1) 128) ; otherwise [b 128, K)
+  const bool maskA = left, maskB = !left;
+  const bool keep_ge = left == (p.tri_eff_upper != 0);
+  const int64_t ksa = AK ? kstep : (int64_t)kstep * p.lda, ksb = BKC ? kstep : (int64_t)kstep * p.ldb;
+  const int64_t qsa = AK ? 32 * p.lda : TRANSPOSE_STAGE ? 8 * p.lda : (512 / TS) * p.lda;
+  const int64_t qsa2 = AK ? 64 * p.lda : TRANSPOSE_STAGE ? 16 : 2 * (512 / TS) * p.lda;
+  const int64_t qsb = BKC ? 32 * p.ldb : TRANSPOSE_STAGE ? 8 * p.ldb : (512 / TS) * p.ldb;
+  const int64_t qsb2 = BKC ? 64 * p.ldb : TRANSPOSE_STAGE ? 16 : 2 * (512 / TS) * p.ldb;
+
+  for (int ph = 0; ph < 2; ++ph) {
+    const bool asc = (ph == 0) == anchor0;                 // phase 0 leaves the anchor, phase 1 returns to it
+    const int bt = asc ? pb : ntri - 1 - pb;               // anchor 0: short tile pb, long tile ntri - 1 - pb; anchor K: the reverse
+    const int ti = left ? bt : fr, tj = left ? fr : bt;
+    const int i0 = ti * BM, j0 = tj * BN, d0 = left ? i0 : j0;
+    const int klo = anchor0 ? 0 : d0, khi = anchor0 ? d0 + TS : p.K;
+    const int ntk = (khi - klo) / kstep;
+    const int tb0 = (d0 - klo) / BK, tb1 = tb0 + TS / BK;  // panels [tb0, tb1) cross the diagonal of the triangular operand
+
+    d4_t acc[SUB][SUB];
+#pragma unroll
+    for (int a = 0; a < SUB; ++a)
+#pragma unroll
+      for (int c = 0; c < SUB; ++c) acc[a][c] = (d4_t){0.0, 0.0, 0.0, 0.0};
+
+    // per-thread source of panel 0 (see panel_load for the thread -> element map)
+    const double* const fa0 = AK ? p.A + (int64_t)(i0 + (tid >> 3)) * p.lda + klo + 2 * (tid & 7)
+                              : TRANSPOSE_STAGE ? p.A + (int64_t)(klo + rc_k(tid, 0)) * p.lda + i0 + rc_r<TS>(tid, 0)
+                                                : p.A + (int64_t)(klo + tid / (TS / 2)) * p.lda + i0 + 2 * (tid & (TS / 2 - 1));
+    const double* const fb0 = BKC ? p.B + (int64_t)(j0 + (tid >> 3)) * p.ldb + klo + 2 * (tid & 7)
+                              : TRANSPOSE_STAGE ? p.B + (int64_t)(klo + rc_k(tid, 0)) * p.ldb + j0 + rc_r<TS>(tid, 0)
+                                                : p.B + (int64_t)(klo + tid / (TS / 2)) * p.ldb + j0 + 2 * (tid & (TS / 2 - 1));
+    const double* fa = fa0;
+    const double* fb = fb0;
+    const int64_t sa = asc ? ksa : -ksa, sb = asc ? ksb : -ksb;
+    const int dir = asc ? 1 : -1;
+    int t = asc ? 0 : ntk - 1;
+
+    d2_t ra[NQ], rb[NQ];
+    {
+      const int kf = klo + t * kstep;
+      panel_load<TS, AK>(p.A, p.lda, i0, p.M, kf, khi, tid, 1, ra);
+      panel_load<TS, BKC>(p.B, p.ldb, j0, p.N, kf, khi, tid, 1, rb);
+      if (maskA && t >= tb0 && t < tb1) panel_mask<TS, AK>(i0, kf, tid, keep_ge, p.tri_unit, ra);
+      if (maskB && t >= tb0 && t < tb1) panel_mask<TS, BKC>(j0, kf, tid, keep_ge, p.tri_unit, rb);
+      panel_store<TS, AK>(lds, tid, ra);
+      panel_store<TS, BKC>(lds + TILE_LDS, tid, rb);
+    }
+    __syncthreads();
+
+    int par = 0;
+    auto iterate = [&](const int tc, const int tnext, auto fast_tag) {
+      constexpr bool FAST = decltype(fast_tag)::value;
+      const double* La = lds + par * STAGE_LDS;
+      const double* Lb = La + TILE_LDS;
+      const int kn = klo + tnext * kstep;
+      const bool more = FAST || (tnext >= 0);
+      if (FAST) {
+        fa += sa;
+        fb += sb;
+        if (LOADS_IN_SHADOW) __builtin_amdgcn_s_setprio(1);
+        panel_load_fast<TS>(fa, qsa, qsa2, ra);
+        panel_load_fast<TS>(fb, qsb, qsb2, rb);
+      } else if (more) {
+        panel_load<TS, AK>(p.A, p.lda, i0, p.M, kn, khi, tid, 1, ra);
+        panel_load<TS, BKC>(p.B, p.ldb, j0, p.N, kn, khi, tid, 1, rb);
+      }
+      unsigned keep = (1u << (SUB * SUB)) - 1u;
+      if (!FAST) {
+        const int kk = klo + tc * kstep;
+        if (tc >= tb0 && tc < tb1 && !p.no_skip) {
+#pragma unroll
+          for (int a = 0; a < SUB; ++a)
+#pragma unroll
+            for (int c = 0; c < SUB; ++c) {
+              bool on;
+              if (left) {
+                const int rlo = i0 + wm * (TS / 2) + 16 * a;
+                on = p.tri_eff_upper ? (kk + BK - 1 >= rlo) : (kk <= rlo + 15);
+              } else {
+                const int clo = j0 + wn * (TS / 2) + 16 * c;
+                on = p.tri_eff_upper ? (kk <= clo + 15) : (kk + BK - 1 >= clo);
+              }
+              if (!on) keep &= ~(1u << (a * SUB + c));
+            }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        d2_t af[SUB], bf[SUB];
+#pragma unroll
+        for (int a = 0; a < SUB; ++a) af[a] = frag_read<TS, AK>(La, wm * (TS / 2) + a * 16 + r16, u, g);
+#pragma unroll
+        for (int c = 0; c < SUB; ++c) bf[c] = frag_read<TS, BKC>(Lb, wn * (TS / 2) + c * 16 + r16, u, g);
+        if (!(FAST && LOADS_IN_SHADOW)) __builtin_amdgcn_s_setprio(1);
+        mfma_step<SUB, 0, FAST>(acc, af, bf, keep);
+        mfma_step<SUB, 1, FAST>(acc, af, bf, keep);
+        if (FAST && STORE_IN_SHADOW && u == 1) {
+          double* Na = lds + (par ^ 1) * STAGE_LDS;
+          panel_store<TS, AK>(Na, tid, ra);
+          panel_store<TS, BKC>(Na + TILE_LDS, tid, rb);
+          if (LOADS_IN_SHADOW) {                                   // the pinned schedule of dgemm_tile_kernel's FAST iteration
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * SUB, 0);
+#pragma unroll
+            for (int i = 0; i < 2 * NQ; ++i) {
+              __builtin_amdgcn_sched_group_barrier(0x008, (SUB * SUB) / (2 * NQ), 0);
+              __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 2 * SUB; ++i) {
+              __builtin_amdgcn_sched_group_barrier(0x008, (SUB * SUB) / (2 * SUB), 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < NW; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, (2 * SUB * SUB) / NW > 0 ? (2 * SUB * SUB) / NW : 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+          }
+        }
+        if (!(FAST && LOADS_IN_SHADOW) || u == 1) __builtin_amdgcn_s_setprio(0);
+      }
+      if (more && !(FAST && STORE_IN_SHADOW)) {
+        if (!FAST) {
+          if (maskA && tnext >= tb0 && tnext < tb1) panel_mask<TS, AK>(i0, kn, tid, keep_ge, p.tri_unit, ra);
+          if (maskB && tnext >= tb0 && tnext < tb1) panel_mask<TS, BKC>(j0, kn, tid, keep_ge, p.tri_unit, rb);
+        }
+        double* Na = lds + (par ^ 1) * STAGE_LDS;
+        panel_store<TS, AK>(Na, tid, ra);
+        panel_store<TS, BKC>(Na + TILE_LDS, tid, rb);
+      }
+      par ^= 1;
+      __syncthreads();
+    };
+    // number of FAST iterations that can start at panel tc: the panel multiplied AND its successor clear of the diagonal band
+    auto fast_run = [&](int tc) -> int {
+      if (asc) return tc < tb0 ? max(0, min(tb0, ntk) - 1 - tc) : (tc >= tb1 ? max(0, ntk - 1 - tc) : 0);
+      return tc >= tb1 ? tc - tb1 : (tc < tb0 ? tc : 0);
+    };
+    while (t >= 0 && t < ntk) {
+      const int nf = fast_run(t);
+      fa = fa0 + (int64_t)t * ksa;
+      fb = fb0 + (int64_t)t * ksb;
+      for (int q = 0; q < nf; ++q, t += dir) iterate(t, t + dir, std::true_type{});
+      while (t >= 0 && t < ntk) {
+        const int tn = t + dir;
+        iterate(t, (tn >= 0 && tn < ntk) ? tn : -1, std::false_type{});
+        t = tn;
+        if (t >= 0 && t < ntk && fast_run(t) > 0) break;
+      }
+    }
+
+    // epilogue (beta == 0): lane holds C[i = ..+r16][j = ..+g+4*reg]; 16 lanes -> 128 contiguous bytes of one column
+#pragma unroll
+    for (int a = 0; a < SUB; ++a) {
+      const int i = i0 + wm * (TS / 2) + a * 16 + r16;
+#pragma unroll
+      for (int c = 0; c < SUB; ++c)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int j = j0 + wn * (TS / 2) + c * 16 + g + 4 * reg;
+          p.C[i + (int64_t)j * p.ldc] = p.alpha * acc[a][c][reg];
         }
     }
   }
@@ -1498,6 +1720,12 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
   p.b_vec = (((uintptr_t)p.B & 15) == 0) && ((p.ldb & 1) == 0);
   p.no_skip = getenv("CAPI_NO_SKIP") ? 1 : 0;
   p.share_ab = (p.out_uplo >= 0 && p.A == p.B && p.lda == p.ldb && ak == bkc && !getenv("CAPI_NO_SHARE")) ? 1 : 0;
+  {
+    static const int order_mode = getenv("CAPI_TILE_ORDER") ? atoi(getenv("CAPI_TILE_ORDER")) : 1;
+    static const int order_min = getenv("CAPI_TILE_ORDER_MIN") ? atoi(getenv("CAPI_TILE_ORDER_MIN")) : 16;
+    p.order = 0;
+    if (p.out_uplo >= 0 && (order_mode & 1) && p.tiles_n >= order_min) p.order |= 1;
+  }
   p.splitk = 1;
   p.k_per_split = p.K;
   p.k_rotate = 0;
@@ -1557,6 +1785,7 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
                  : (p.tri_side >= 0 ? (double)p.M * (double)p.N * (double)p.K : 2.0 * (double)p.M * (double)p.N * (double)p.K);
     rec->flops *= share;
     rec->variant = (ak ? 2 : 0) + (bkc ? 1 : 0) + (p.ts == 128 ? 0 : 4);
+    rec->m = p.M; rec->n = p.N; rec->k = p.K; rec->kind = p.out_uplo >= 0 ? 1 : (p.tri_side >= 0 ? 2 : 0);
     CAPI_HIP_CHECK(h, hipEventRecord(rec->e0, s));
     return CAPI_OK;
   };
@@ -1572,6 +1801,32 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
   // are the lookahead's rectangles only -- the step's fabric traffic falls by 5 % (3625 -> 3437 GB at n = 65536), its time does
   // not change, and the per-launch durations the roofline is computed from stretch, because the round launches of a low-priority
   // bulk stream queue behind the chain's kernels at every boundary (0.876 -> 0.825 on the same box).
+  // TRMM in tile pairs (dtrmm_pair_kernel): equal work per workgroup, the launch of a plain product
+  {
+    static const int pair_mode = getenv("CAPI_TRMM_PAIR") ? atoi(getenv("CAPI_TRMM_PAIR")) : 1;
+    // Measured (tools/pair_window.py, all three forms of the recursion): a launch of exactly one resident round +8..10 % (order 4096:
+    // 63 -> 68.5 TFLOP/s; 2048 x 8192: 51..55 -> 55..59), two rounds +2..3 %, four +0.5..1 %, nine +-0.5 %; a launch that is NOT whole
+    // rounds loses (1152 workgroups, order 6144: 68.3 -> 61.5 -- the equal, long workgroups of the last 128 cost a third round).
+    // L2-to-fabric traffic does not change (order 32768: 2 x FETCH_SIZE 1.19 -> 1.22 TB).  Pairs therefore run up to four whole rounds
+    // (CAPI_TRMM_PAIR=2: whenever the launch is whole rounds; =0: never); larger products keep the longest-first order.
+    const int ntri_ = p.tri_side == CAPI_LEFT ? p.tiles_m : p.tiles_n, nfree_ = p.tri_side == CAPI_LEFT ? p.tiles_n : p.tiles_m;
+    const int64_t wgs = (int64_t)(ntri_ / 2) * nfree_;
+    if (pair_mode && tri && !p.tri_dense && !p.tri_block && p.tri_koff == 0 && p.ts == 128 && p.splitk == 1 && p.beta == 0.0 && p.batch <= 1 &&
+        p.M % 128 == 0 && p.N % 128 == 0 && p.K % 128 == 0 && p.a_vec && p.b_vec && (ntri_ & 1) == 0 &&
+        wgs % per_round == 0 && (pair_mode > 1 || wgs <= 4 * per_round)) {
+      gemm_kernel_t kp = ak ? (bkc ? dtrmm_pair_kernel<true, true> : dtrmm_pair_kernel<true, false>)
+                            : (bkc ? dtrmm_pair_kernel<false, true> : dtrmm_pair_kernel<false, false>);
+      CAPI_RAISE_LDS_LIMIT(h, CAPI_ATTR_PAIR0 + (ak ? 2 : 0) + (bkc ? 1 : 0), kp, lds_bytes);
+      capi_handle_s::prof_rec* rec;
+      int rc = prof_open(1.0, rec);
+      if (rc != CAPI_OK) return rc;
+      if (rec) rec->variant += 16;                                      // its own kernel symbol: not counted with dgemm_tile_kernel's launches
+      hipLaunchKernelGGL(kp, dim3((unsigned)wgs), dim3(NTHREADS), lds_bytes, s, p);
+      if (rec) CAPI_HIP_CHECK(h, hipEventRecord(rec->e1, s));
+      CAPI_HIP_CHECK(h, hipGetLastError());
+      return CAPI_OK;
+    }
+  }
   if (use_rounds) {
     for (int64_t base = 0; base < nblk; base += per_round) {
       GemmArgs q = p;
@@ -1818,6 +2073,10 @@ int capi_prof_collect(capi_handle_t h, int variant, int64_t* launches, double* t
     CAPI_HIP_CHECK(h, hipEventElapsedTime(&ms, h->prof[i].e0, h->prof[i].e1));
     *launches += 1; *total_ms += ms; *total_flops += h->prof[i].flops;
     if (max_ms && ms > *max_ms) *max_ms = ms;
+    static const bool dump = getenv("CAPI_PROF_DUMP") != nullptr;       // diagnostics: one line per recorded launch
+    if (dump && variant < 0)
+      fprintf(stderr, "[capi prof] %4d %s v%d M=%d N=%d K=%d  %9.3f ms  %6.2f TF/s\n", i, h->prof[i].kind == 0 ? "gemm" : h->prof[i].kind == 1 ? "syrk" : "trmm",
+              h->prof[i].variant, h->prof[i].m, h->prof[i].n, h->prof[i].k, ms, h->prof[i].flops / ms * 1e-9);
   }
   return CAPI_OK;
 }

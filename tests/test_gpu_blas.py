@@ -242,6 +242,37 @@ def test_tall_products_wider_than_256(n, pad, uplo, trans, alpha, beta):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("side,uplo,trans,diag", list(itertools.product((0, 1), (0, 1), (0, 1), (0, 1))))
+@pytest.mark.parametrize("ntri,nfree", [(4096, 4096), (2048, 8192), (8192, 4096)])
+def test_dtrmm_tile_pairs(side, uplo, trans, diag, ntri, nfree):
+    """Orders from 4096 up run as tile PAIRS (gemm_f64.hip: dtrmm_pair_kernel: tile b and tile ntri - 1 - b in one workgroup, the
+    second walked backwards in k): all sixteen forms against a plain fp64 product of the masked triangle, 1e-12 relative; the
+    in-place form must give the same bits as the out-of-place one."""
+    import torch
+    from capital_amd import capi
+    if diag and ntri != 4096:
+        pytest.skip("unit diagonal is covered at the square size")
+    h = capi.Handle(0)
+    torch.manual_seed(side * 8 + uplo * 4 + trans * 2 + diag)
+    m, n = (ntri, nfree) if side == 0 else (nfree, ntri)
+    Tt = torch.rand((ntri, ntri), dtype=torch.float64, device="cuda") - 0.5     # column-major T = Tt^T, junk in the unreferenced triangle
+    Bt = torch.rand((n, m), dtype=torch.float64, device="cuda") - 0.5           # column-major m x n
+    Ct = torch.full((n, m), float("nan"), dtype=torch.float64, device="cuda")   # beta == 0: never read
+    Te = torch.tril(Tt) if uplo == 1 else torch.triu(Tt)
+    if diag:
+        Te = Te - torch.diag(torch.diagonal(Te)) + torch.eye(ntri, dtype=torch.float64, device="cuda")
+    opTt = Te if trans == 0 else Te.T                                            # op(T)^T
+    ref = -1.5 * (Bt @ opTt if side == 0 else opTt @ Bt)
+    torch.cuda.synchronize()
+    h.call("capi_dtrmm_oop", side, uplo, trans, diag, m, n, -1.5, capi.ptr(Tt), ntri, capi.ptr(Bt), m, capi.ptr(Ct), m)
+    h.sync()
+    assert (Ct - ref).abs().max().item() <= 1e-12 * ref.abs().max().item()
+    h.call("capi_dtrmm", side, uplo, trans, diag, m, n, -1.5, capi.ptr(Tt), ntri, capi.ptr(Bt), m)
+    h.sync()
+    assert torch.equal(Bt, Ct)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,k", [(5000, 300), (6016, 200)])
 def test_partial_last_round_is_recut_into_64_tiles(n, k):
     """Orders whose 128-tiling leaves a partial last round (1600 = 3 x 512 + 64 tiles for gemm 5000, 1128 = 2 x 512 + 104

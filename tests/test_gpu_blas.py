@@ -273,6 +273,31 @@ def test_dtrmm_tile_pairs(side, uplo, trans, diag, ntri, nfree):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("uplo", (0, 1))
+@pytest.mark.parametrize("n,k", [(2304, 512), (4480, 192), (6016, 200)])
+def test_triangular_output_in_bands(uplo, n, k):
+    """From 16 tile rows up a triangular output's tiles are enumerated in bands of 8 tile rows (gemm_f64.hip: tile_of_dims), also in
+    the 64-tile re-cut of a partial last round: every element of the wanted triangle is produced exactly once (beta = 1 on a known C
+    would show a tile computed twice), the other triangle is untouched."""
+    import torch
+    from capital_amd import capi
+    h = capi.Handle(0)
+    torch.manual_seed(n + uplo)
+    A = torch.rand((n, k), dtype=torch.float64, device="cuda") - 0.5     # column-major k x n
+    C0 = torch.rand((n, n), dtype=torch.float64, device="cuda")
+    C1 = C0.clone()
+    torch.cuda.synchronize()
+    h.call("capi_dsyrk", uplo, 1, n, k, -1.0, capi.ptr(A), k, 1.0, capi.ptr(C1), n)      # wanted triangle of C -= A^T A
+    h.sync()
+    full = C0 - A @ A.T
+    # column-major upper triangle == lower triangle of the row-major tensor
+    want, keep = (torch.tril, torch.triu) if uplo == 1 else (torch.triu, torch.tril)
+    assert (want(C1) - want(full)).abs().max().item() <= 1e-13 * full.abs().max().item()
+    off = 1 if uplo == 1 else -1
+    assert torch.equal(keep(C1, off), keep(C0, off))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,k", [(5000, 300), (6016, 200)])
 def test_partial_last_round_is_recut_into_64_tiles(n, k):
     """Orders whose 128-tiling leaves a partial last round (1600 = 3 x 512 + 64 tiles for gemm 5000, 1128 = 2 x 512 + 104

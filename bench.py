@@ -72,9 +72,12 @@ def cpu_baseline(n_sample, m_sample, qn):
         res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
         js = json.loads(res.stdout.strip().splitlines()[-1])
     except Exception as e:   # the baseline is a reported extra: its failure must not take the GPU numbers with it
-        return {"value": None, "unit": "TFLOP/s", "cores": None, "kind": "failed", "sample": f"oracle.host_baseline failed: {e!r}"[:300]}
+        return {"value": None, "unit": "TFLOP/s", "cores": None, "kind": "port", "sample": f"oracle.host_baseline failed: {e!r}"[:300]}
     ch, qr = js.get("cholesky", {}), js.get("cacqr2", {})
-    return {"value": ch.get("tflops"), "unit": "TFLOP/s", "cores": js["cores"], "kind": js["kind"], "library": js["library"],
+    # `kind` keeps to the contract's two values: "port" = the oracle's restatement of the reference's schedule ("reference" would be the
+    # reference's own build, which this image cannot make: no mkl.h).  `blas` says who does the arithmetic inside it.
+    return {"value": ch.get("tflops"), "unit": "TFLOP/s", "cores": js["cores"], "kind": "port",
+            "blas": "host-blas" if js["kind"] == "host-blas" else "the oracle's own kernels (no host BLAS found)", "library": js["library"],
             "library_path": js["library_path"],
             "sample": f"n={n_sample} recursive Cholesky with inverse (same generator and schedule, bc_mult={ch.get('bc_mult')}), "
                       f"{ch.get('seconds', 0):.2f} s, faster of two runs; whole leg {time.perf_counter() - t0:.0f} s",

@@ -17,13 +17,15 @@
 //   * split-K (tall-skinny Gram matrices of CholeskyQR2) writes per-slice partial tiles to a slab that a
 //     second kernel reduces in a fixed order (bit-reproducible, no atomics);
 //   * workgroup ids are re-dealt so that the 64 tiles an XCD runs concurrently form a compact block
-//     of the output (8 XCDs x private 4 MiB L2).
-// Around it, in this file: dgemm_small_kernel (order <= 512: 32 x 32 tiles, K in 256-deep bursts -- the recursion's
+//     of the output (8 XCDs x private 4 MiB L2): bands of 8 tile rows, for full and for triangular outputs alike.
+// Around it, in this file: dtrmm_pair_kernel (a TRMM whose launch is whole resident rounds: two tiles of complementary k-range per
+// workgroup, the second walked backwards in k), dgemm_small_kernel (order <= 512: 32 x 32 tiles, K in 256-deep bursts -- the recursion's
 // latency-bound levels), gram_ts_kernel and trmm_right_ts32_kernel (CholeskyQR2's tall-skinny Gram matrix and Q = A R^-1,
 // full-width workgroups that read the tall operand once), and launch_gemm, which picks between them with a makespan
 // model in CU-cycles.
 // Diagnostic environment switches (read once): CAPI_DEBUG_GEMM (print every choice), CAPI_FORCE_TS=64|128, CAPI_SMALL=0|1,
-// CAPI_NO_TS, CAPI_TS_ROWS16, CAPI_NO_SHARE, CAPI_NO_SKIP, CAPI_NO_ROTATE, CAPI_NO_TAIL, CAPI_THIN_ROUNDS, CAPI_PEAK_BLOCKS_PER_CU.
+// CAPI_NO_TS, CAPI_TS_ROWS16, CAPI_NO_SHARE, CAPI_NO_SKIP, CAPI_NO_ROTATE, CAPI_NO_TAIL, CAPI_THIN_ROUNDS, CAPI_PEAK_BLOCKS_PER_CU,
+// CAPI_TILE_ORDER=0, CAPI_TRMM_PAIR=0|2, CAPI_ROUNDS=1, CAPI_PROF_DUMP.
 #include "capi_internal.h"
 #include <type_traits>
 

@@ -73,6 +73,8 @@ int capi_destroy(capi_handle_t h) {
   if (h->h_info) (void)hipHostFree(h->h_info);
   for (int i = 0; i < h->prof_cap; ++i) if (h->prof[i].e0) { (void)hipEventDestroy(h->prof[i].e0); (void)hipEventDestroy(h->prof[i].e1); }
   free(h->prof);
+  for (int i = 0; i < h->graphs_n; ++i) if (h->graphs[i].exec) (void)hipGraphExecDestroy(h->graphs[i].exec);
+  free(h->graphs);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->owns_stream && h->stream) (void)hipStreamDestroy(h->stream);

@@ -44,6 +44,10 @@ struct capi_handle_s {
   // kernels whose dynamic-LDS limit has been raised on THIS handle's device (hipFuncSetAttribute is per device; a
   // process-wide flag would leave a second device's copy of the kernel at the default limit)
   uint32_t lds_attr_done = 0;
+  // captured launch sequences of the blocked diagonal-block routine, one per (block, order): factor_f64.hip
+  struct graph_ent { int64_t n, lda, ldx; double *A, *X; void* w; hipStream_t s; hipGraphExec_t exec; int seen; };
+  graph_ent* graphs = nullptr;
+  int graphs_n = 0, graphs_cap = 0;
   char err[512] = {0};
 };
 

@@ -691,16 +691,79 @@ int capi_dpotrf_trtri(capi_handle_t h, int64_t n, double* A, int64_t lda, double
   if (n <= LEAF) return leaf_launch(h, A, lda, Rinv, ldi, (int)n, 1, 1, 0, 0, 0);
   void* w;
   RC(capi_ws2_get(h, sizeof(double) * ((size_t)(n / 2 + LEAF) * (size_t)(n / 2 + LEAF) + (size_t)LEAF * (size_t)n), &w));
-  {
-    dim3 grid((unsigned)cdiv(n, 256), (unsigned)(n < 65535 ? n : 65535));
-    hipLaunchKernelGGL(trizero2_kernel, grid, dim3(256), 0, h->stream, n, A, lda, Rinv, ldi);
-    CAPI_HIP_CHECK(h, hipGetLastError());
-  }
   // up to order 4096 the blocked schedule's shorter launch chain wins; above, the recursion's large products do
   static const char* force = getenv("CAPI_POTRF_TRTRI");   // "rec" | "blocked": diagnostics
   const bool blocked = force ? force[0] == 'b' : n <= 4096;
-  if (blocked) return potrf_trtri_blocked(h, n, A, lda, Rinv, ldi, 0, (double*)w);
-  return potrf_trtri_rec(h, n, A, lda, Rinv, ldi, 0, 0);
+  auto run = [&]() -> int {
+    dim3 grid((unsigned)cdiv(n, 256), (unsigned)(n < 65535 ? n : 65535));
+    hipLaunchKernelGGL(trizero2_kernel, grid, dim3(256), 0, h->stream, n, A, lda, Rinv, ldi);
+    CAPI_HIP_CHECK(h, hipGetLastError());
+    if (blocked) return potrf_trtri_blocked(h, n, A, lda, Rinv, ldi, 0, (double*)w);
+    return potrf_trtri_rec(h, n, A, lda, Rinv, ldi, 0, 0);
+  };
+  // The blocked routine is a fixed chain of ~6 launches per 128 columns, each a few microseconds long: the second time the same
+  // block comes by (same pointers, order and scratch: the next factor() of the same matrix) the chain is captured into a hipGraph,
+  // from the third on it is replayed -- one submission instead of ~50 per order-1024 block.  (CAPI_GRAPH=1; off by default.)
+  static const int graph_mode = getenv("CAPI_GRAPH") ? atoi(getenv("CAPI_GRAPH")) : 0;
+  if (!graph_mode || !blocked || n > 2048) return run();
+  capi_handle_s::graph_ent* e = nullptr;
+  for (int i = 0; i < h->graphs_n; ++i) {
+    auto& g = h->graphs[i];
+    if (g.n == n && g.A == A && g.X == Rinv && g.lda == lda && g.ldx == ldi && g.w == w && g.s == h->stream) { e = &g; break; }
+  }
+  if (!e) {
+    if (h->graphs_n == h->graphs_cap) {
+      const int ncap = h->graphs_cap ? 2 * h->graphs_cap : 128;
+      if (ncap > 4096) return run();
+      auto* ng = (capi_handle_s::graph_ent*)realloc(h->graphs, sizeof(capi_handle_s::graph_ent) * ncap);
+      if (!ng) return run();
+      h->graphs = ng; h->graphs_cap = ncap;
+    }
+    h->graphs[h->graphs_n++] = capi_handle_s::graph_ent{n, lda, ldi, A, Rinv, w, h->stream, nullptr, 1};
+    if (graph_mode > 1) fprintf(stderr, "[capi graph] order %lld first seen\n", (long long)n);
+    return run();
+  }
+  if (e->exec) {
+    if (graph_mode > 1) fprintf(stderr, "[capi graph] order %lld replayed\n", (long long)n);
+    CAPI_HIP_CHECK(h, hipGraphLaunch(e->exec, h->stream));
+    return CAPI_OK;
+  }
+  if (e->seen < 0) return run();
+  // capture: nothing in the chain may allocate (the first pass sized every workspace) or record profile events
+  const bool prof_was = h->prof_on;
+  h->prof_on = false;
+  hipGraph_t graph = nullptr;
+  int rc = CAPI_OK;
+  const hipError_t eb = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal);
+  if (eb != hipSuccess) {
+    if (graph_mode > 1) fprintf(stderr, "[capi graph] begin capture refused: %s (stream %p)\n", hipGetErrorString(eb), (void*)h->stream);
+    h->prof_on = prof_was; e->seen = -1; (void)hipGetLastError(); return run();
+  }
+  rc = run();
+  const hipError_t ee = hipStreamEndCapture(h->stream, &graph);
+  h->prof_on = prof_was;
+  if (rc != CAPI_OK || ee != hipSuccess || !graph) {
+    if (graph_mode > 1) fprintf(stderr, "[capi graph] capture failed: rc %d (%s), end capture: %s\n", rc, h->err, hipGetErrorString(ee));
+    if (graph) (void)hipGraphDestroy(graph);
+    (void)hipGetLastError();
+    e->seen = -1;                                     // this block keeps to plain launches
+    return run();
+  }
+  hipGraphExec_t exec = nullptr;
+  const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (ei != hipSuccess || !exec) {
+    if (graph_mode > 1) fprintf(stderr, "[capi graph] instantiate failed: %s\n", hipGetErrorString(ei));
+    (void)hipGetLastError(); e->seen = -1; return run();
+  }
+  e->exec = exec;
+  if (graph_mode > 1) {
+    size_t nodes = 0;
+    fprintf(stderr, "[capi graph] order %lld captured\n", (long long)n);
+    (void)nodes;
+  }
+  CAPI_HIP_CHECK(h, hipGraphLaunch(exec, h->stream));
+  return CAPI_OK;
 }
 
 int capi_dpotrf(capi_handle_t h, int uplo, int64_t n, double* A, int64_t lda) {

@@ -186,3 +186,21 @@ def test_geqrf_tall_ill_conditioned_falls_back(hip, oracle):
     Q = capi.to_host(dA)
     assert np.abs(Q.T @ Q - np.eye(n)).max() <= 1e-13
     assert np.abs(Q @ R - A).max() <= 1e-13 * np.abs(A).max() * n
+
+
+@pytest.mark.gpu
+def test_diagonal_block_routine_replayed_from_a_graph():
+    """CAPI_GRAPH: the blocked diagonal-block routine captured into a hipGraph on its second call for the same block and replayed from
+    the third on (factor_f64.hip: capi_dpotrf_trtri).  Off by default -- measured 1 % slower than plain launches --
+    but it must stay correct: the probe factors the same blocks eight times and reports the residuals of the LAST (replayed) result."""
+    import os, re, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "graph_probe.py")], env=dict(os.environ, CAPI_GRAPH="2"), cwd=root,
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = res.stdout + res.stderr
+    assert out.count("order 1024 captured") == 1 and out.count("order 1024 replayed") >= 5, out[-2000:]
+    vals = re.findall(r"\|R\^T R - S\| ([0-9.e+-]+)  \|Rinv R - I\| ([0-9.e+-]+)", out)
+    assert len(vals) == 2
+    for a, b in vals:
+        assert float(a) <= 1e-14 and float(b) <= 1e-13

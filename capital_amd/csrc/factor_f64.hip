@@ -766,6 +766,13 @@ int capi_dpotrf_trtri(capi_handle_t h, int64_t n, double* A, int64_t lda, double
   return CAPI_OK;
 }
 
+// doubles of scratch-2 the upper-case capi_dpotrf uses: room for the recursion's temporaries, the diagonal block's inverse, and
+// the blocked routine's row panel + pair products
+static size_t potrf_upper_scratch(int64_t n) {
+  const size_t nb0 = (size_t)(n < 1024 ? n : 1024);
+  return nb0 * nb0 * 2 + (size_t)LEAF * nb0 + (nb0 / 2 + LEAF) * (nb0 / 2 + LEAF);
+}
+
 int capi_dpotrf(capi_handle_t h, int uplo, int64_t n, double* A, int64_t lda) {
   CAPI_REQUIRE(h, h, "null handle");
   CAPI_REQUIRE(h, ok01(uplo), "uplo code");
@@ -775,8 +782,9 @@ int capi_dpotrf(capi_handle_t h, int uplo, int64_t n, double* A, int64_t lda) {
   // cholinv.hpp:9 -- the hot path only ever factors 'U'.  'L' is served by factoring the transpose.
   if (uplo == CAPI_LOWER) {
     void* w;
-    RC(capi_ws2_get(h, sizeof(double) * (size_t)n * (size_t)n * 3, &w));
-    double* U = (double*)w + (size_t)n * n * 2;  // the upper-case call below uses at most the first 2*n*n
+    const size_t inner = potrf_upper_scratch(n);      // what the upper-case call below takes from the front of this block
+    RC(capi_ws2_get(h, sizeof(double) * (inner + (size_t)n * (size_t)n), &w));
+    double* U = (double*)w + inner;
     dim3 grid((unsigned)cdiv(n, 256), (unsigned)(n < 65535 ? n : 65535));
     hipLaunchKernelGGL(transpose_tri_kernel, grid, dim3(256), 0, h->stream, A, lda, U, n, n, 0);
     CAPI_HIP_CHECK(h, hipGetLastError());
@@ -789,18 +797,23 @@ int capi_dpotrf(capi_handle_t h, int uplo, int64_t n, double* A, int64_t lda) {
   const int64_t NB = 1024;
   if (n <= LEAF) return leaf_launch(h, A, lda, A, lda, (int)n, 0, 0, 0, 0, 0);
   const int64_t nb0 = n < NB ? n : NB;
-  double* Xd = nullptr;
+  double *Xd = nullptr, *Wb = nullptr;
+  // the diagonal blocks by the blocked routine (3 dependent launches per 128 columns) instead of the halving recursion (5 + a copy):
+  // order 1024 0.51 against 0.7 ms.  (CAPI_POTRF_DIAG=rec: the recursion, A/B)
+  static const bool diag_rec = getenv("CAPI_POTRF_DIAG") && getenv("CAPI_POTRF_DIAG")[0] == 'r';
   {
     // diag inverse lives in its own allocation slice: first nb0*nb0 doubles of scratch-2 are used by the
-    // recursion's temporaries only up to (nb0/2)^2, so place Xd after them.
+    // recursion's temporaries only up to (nb0/2)^2, so place Xd after them; the blocked routine's scratch follows
     void* w2;
-    RC(capi_ws2_get(h, sizeof(double) * (size_t)nb0 * nb0 * 2, &w2));
+    RC(capi_ws2_get(h, sizeof(double) * potrf_upper_scratch(n), &w2));
     Xd = (double*)w2 + (size_t)nb0 * nb0;
+    Wb = Xd + (size_t)nb0 * nb0;
   }
   for (int64_t j0 = 0; j0 < n; j0 += NB) {
     const int64_t jb = (n - j0) < NB ? (n - j0) : NB, rest = n - j0 - jb;
     double* Ajj = A + j0 + j0 * lda;
-    RC(potrf_trtri_rec(h, jb, Ajj, lda, Xd, nb0, 0, (int)j0));
+    if (diag_rec) RC(potrf_trtri_rec(h, jb, Ajj, lda, Xd, nb0, 0, (int)j0));
+    else RC(potrf_trtri_blocked(h, jb, Ajj, lda, Xd, nb0, (int)j0, Wb));
     if (rest > 0) {
       double* A12 = A + j0 + (j0 + jb) * lda;
       RC(capi_dtrmm(h, CAPI_LEFT, CAPI_UPPER, CAPI_TRANS, CAPI_NONUNIT, jb, rest, 1.0, Xd, nb0, A12, lda));

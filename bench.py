@@ -230,6 +230,9 @@ def main():
         out["config2"] = {"workload": f"n={n2} recursive Cholesky with inverse on 1 GPU (BASELINE config 2)", "tflops": r2["tflops"],
                           "ms_per_step": r2["ms_per_step"], "residual": r2["residual"],
                           "roofline_kernel_tflops": k2["flops"] / (k2["ms"] * 1e-3) / 1e12 if k2["ms"] > 0 else None}
+        # BASELINE words config 2 as "panel POTRF + TRSM + trailing SYRK": the same matrix in TRSM mode (R only, no inverse formed)
+        r2t = time_cholesky(driver, L, h, n2, 1, bc_mult_for(n2, 1, 1, BASE_CASE_ORDER), 0, max(args.steps, 3), 1, False, device, bc_policy=2, trsm_mode=True)
+        out["config2"]["trsm_mode"] = {"tflops": r2t["tflops"], "ms_per_step": r2t["ms_per_step"], "residual": r2t["residual"]}
 
     if args.gpus == 1 and not args.no_config2 and not args.n:
         # NOT the headline: the same matrix factored without forming any inverse (info::solve_with_trsm: potrf + block TRSM + SYRK,

@@ -324,6 +324,63 @@ def test_partial_last_round_is_recut_into_64_tiles(n, k):
     assert torch.equal(torch.triu(C2, 1), torch.triu(C0, 1))             # the other triangle is untouched
 
 
+@pytest.mark.gpu
+def test_randomized_large_shapes_against_torch():
+    """40 random cases at the orders where the launch rules change (16+ tile rows: banded triangular order; whole-round TRMMs: tile
+    pairs; partial last rounds: the 64-tile re-cut; 64- vs 128-tiles), odd sizes and padded leading dimensions included: syrk / gemmt
+    in all four uplo x trans forms and trmm in all eight side x uplo x trans forms against torch fp64, 1e-12 relative; everything
+    outside the wanted triangle / beyond the rows of C must stay as it was."""
+    import torch
+    from capital_amd import capi
+    h = capi.Handle(0)
+    rng = np.random.default_rng(20261004)
+    dev = "cuda"
+    for case in range(40):
+        kind = case % 2
+        if kind == 0:                                            # C(tri) = alpha op(A)^T-ish product + beta C
+            n = int(rng.choice([2048, 2304, 2560 + 37, 3000, 4096, 4480, 5000 + 1, 6016]))
+            k = int(rng.integers(40, 700))
+            uplo, trans = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+            pad = int(rng.integers(0, 3)) * 2
+            ldc = n + pad
+            # column-major A is k x n when trans == 1 (C = A^T A), n x k otherwise (C = A A^T); row-major tensors hold the transposes
+            rows, cols = (k, n) if trans == 1 else (n, k)
+            lda = rows + pad
+            At = torch.rand((cols, lda), dtype=torch.float64, device=dev) - 0.5
+            Ct0 = torch.rand((n, ldc), dtype=torch.float64, device=dev)
+            Ct = Ct0.clone()
+            torch.cuda.synchronize()
+            h.call("capi_dsyrk", uplo, trans, n, k, -0.75, capi.ptr(At), lda, 0.5, capi.ptr(Ct), ldc)
+            h.sync()
+            Am = At[:, :rows].T                                   # the column-major matrix, logically rows x cols
+            G = (Am.T @ Am) if trans == 1 else (Am @ Am.T)        # n x n, symmetric
+            full = -0.75 * G + 0.5 * Ct0[:, :n].T                 # logical C
+            got = Ct[:, :n].T
+            want = torch.triu if uplo == 1 else torch.tril
+            assert (want(got) - want(full)).abs().max().item() <= 1e-12 * full.abs().max().item(), (case, n, k, uplo, trans)
+            other = torch.tril(got, -1) if uplo == 1 else torch.triu(got, 1)
+            other0 = torch.tril(Ct0[:, :n].T, -1) if uplo == 1 else torch.triu(Ct0[:, :n].T, 1)
+            assert torch.equal(other, other0), (case, "other triangle")
+            assert torch.equal(Ct[:, n:], Ct0[:, n:]), (case, "padding rows")
+        else:
+            ntri = int(rng.choice([2048, 2176, 3072 + 19, 4096, 4096 + 128, 6144, 8192]))
+            nfree = int(rng.choice([1024, 2048 + 5, 4096, 8192]))
+            side, uplo, trans, diag = (int(rng.integers(0, 2)) for _ in range(4))
+            m, n = (ntri, nfree) if side == 0 else (nfree, ntri)
+            Tt = torch.rand((ntri, ntri), dtype=torch.float64, device=dev) - 0.5
+            Bt = torch.rand((n, m), dtype=torch.float64, device=dev) - 0.5
+            Ct = torch.full((n, m), float("nan"), dtype=torch.float64, device=dev)
+            Te = torch.tril(Tt) if uplo == 1 else torch.triu(Tt)
+            if diag:
+                Te = Te - torch.diag(torch.diagonal(Te)) + torch.eye(ntri, dtype=torch.float64, device=dev)
+            opTt = Te if trans == 0 else Te.T
+            ref = 1.25 * (Bt @ opTt if side == 0 else opTt @ Bt)
+            torch.cuda.synchronize()
+            h.call("capi_dtrmm_oop", side, uplo, trans, diag, m, n, 1.25, capi.ptr(Tt), ntri, capi.ptr(Bt), m, capi.ptr(Ct), m)
+            h.sync()
+            assert (Ct - ref).abs().max().item() <= 1e-12 * ref.abs().max().item(), (case, ntri, nfree, side, uplo, trans, diag)
+
+
 def test_randomized_shapes_against_numpy(hip):
     """120 random cases over every BLAS-level entry point, orders 1..700 (crossing the 32-tile burst kernel, the 64- and
     128-tile kernels, split-K and the ragged edges of each), odd leading dimensions, all flag combinations; numpy fp64 as

@@ -1,7 +1,12 @@
 """bench.py -- BASELINE.json's metric on MI355X: whole-job TFLOP/s (algorithmic n^3/3) of the recursive Cholesky
 with inverse (cholesky::cholinv<...>::factor) at n = 65536, inputs resident in HBM, at 1/2/4/8 GPUs of one node.
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 either arrives launched (torch.distributed.run / mpiexec style: RANK, LOCAL_RANK, WORLD_SIZE, MASTER_* in the environment,
+one rank per GPU) or, when WORLD_SIZE is unset, starts its own N ranks the way `mpiexec -n P ./cholinv` starts the reference's bench
+(bench/cholesky/cholinv.cpp:8-13): capital_amd/launch.py -- the launching process makes no GPU call, relays rank 0's JSON line,
+propagates the first non-zero exit and ends the remaining ranks; it refuses at once when the node has fewer than N devices.
 
 One "step" = one factor() call on the reference's synthetic SPD matrix (distribute_symmetric, structure.hpp:68-103).
 The matrix is the metric's own, n = 65536, at EVERY N (strong scaling): N = 1 holds it on one GPU (it fits: 139 GiB with
@@ -49,7 +54,7 @@ def barrier_sync(distributed):
 def max_over_ranks(t, distributed, device):
     if not distributed:
         return t
-    v = torch.tensor([t], dtype=torch.float64, device=device)
+    v = torch.tensor([t], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(v, op=dist.ReduceOp.MAX)
     return float(v.item())
 
@@ -162,7 +167,18 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-qr", action="store_true")
     ap.add_argument("--no-config2", action="store_true")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal only: all N ranks on GPU 0 (needs CAPI_RCCL_LIB = the loopback "
+                    "library of tests/rccl_loopback; RCCL itself refuses two ranks on one device); never a measurement")
     args = ap.parse_args()
+    if args.gpus not in GRID_C:
+        raise SystemExit(f"--gpus must be one of {sorted(GRID_C)} (d*d*c grids of one node)")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not launched: be the launcher (no GPU call in this process, neither before nor after)
+        from capital_amd import launch
+        sys.exit(launch.self_launch(args.gpus, os.path.abspath(__file__), sys.argv[1:], one_device=args.one_device,
+                                    timeout_s=float(os.environ.get("CAPITAL_BENCH_WATCHDOG_S", "1500")) + 120))
+    from capital_amd import launch
+    launch.die_with_parent()
 
     # a hung collective must end the run with a traceback and a non-zero exit, not sit on the node until the driver's limit
     import faulthandler
@@ -171,18 +187,24 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch {args.gpus} ranks (or unset WORLD_SIZE and let bench.py start them)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (the product has no CPU path)")
-    if args.gpus not in GRID_C:
-        raise SystemExit(f"--gpus must be one of {sorted(GRID_C)} (d*d*c grids of one node)")
+    if args.one_device:
+        local_rank = 0
+    elif torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank}, this node shows {torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     from capital_amd import capi, driver
     rccl = None
     if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if args.one_device:
+            dist.init_process_group("gloo")      # torch's side only ships the id and the timing scalars; RCCL proper is the loopback library
+        else:
+            dist.init_process_group("nccl", device_id=device)
         driver.init_distributed(local_rank)
         rccl = driver.world_query()                 # (rank, size) as RCCL reports them for the world communicator
         assert rccl == (rank, world), f"RCCL world communicator reports rank/size {rccl}, launcher says {(rank, world)}"

@@ -92,7 +92,11 @@ def init_distributed(device):
     if size > 1 or os.environ.get("CAPI_RCCL_FORCE"):      # (CAPI_RCCL_FORCE: even a 1-rank communicator goes through RCCL)
         L = capi.load()
         torch_rccl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-        if os.path.exists(torch_rccl):
+        named = os.environ.get("CAPI_RCCL_LIB")          # an RCCL build of the caller's choosing (same ABI), e.g. a debug build
+        if named:
+            if L.capi_comm_load_rccl(named.encode()) != 0:
+                raise DriverError(f"CAPI_RCCL_LIB={named} cannot be loaded as an RCCL library")
+        elif os.path.exists(torch_rccl):
             L.capi_comm_load_rccl(torch_rccl.encode())   # one RCCL per process: the copy torch maps
         buf = (C.c_char * 128)()
         if rank == 0:

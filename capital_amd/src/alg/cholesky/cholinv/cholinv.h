@@ -180,9 +180,14 @@ public:
     CRITTER_STOP(CI::factor);
     // one 4-byte read behind the whole launch chain: a non-SPD input must not come back as NaN factors with status OK
     CAPITAL_CHECK(capi_get_info(capital::handle(), &args.potrf_info));
-    if (args.potrf_info != 0)
-      throw std::domain_error("cholinv::factor: the matrix is not positive definite (non-positive pivot " + std::to_string(args.potrf_info) +
-                              " of a diagonal block); R and Rinv are not valid");
+    // on a grid only the ranks that factored the failing aggregate hold its info word (layer 0 with ReplicateComp, the slice
+    // root with NoReplication[Overlap]): the grid agrees before anyone unwinds, so every rank throws or none does
+    const int failed = capital::ranks_with_nonzero(CommInfo.world, args.potrf_info);
+    if (failed != 0)
+      throw std::domain_error("cholinv::factor: the matrix is not positive definite (" +
+                              (args.potrf_info != 0 ? "non-positive pivot " + std::to_string(args.potrf_info) + " of a diagonal block"
+                                                    : std::string("reported by ") + std::to_string(failed) + " other rank(s) of the grid") +
+                              "); R and Rinv are not valid");
   }
 
   // ---- TRSM mode -----------------------------------------------------------------------------------------------------------

@@ -105,6 +105,23 @@ inline void dev_copy(double* dst, const double* src, int64_t count) {
   CAPITAL_CHECK(capi_memcpy_d2d_async(handle(), dst, src, sizeof(double) * (size_t)count));
 }
 
+// How many ranks of `comm` hold a non-zero status word (collective over comm; one 8-byte all-reduce and one 8-byte read).
+// An error that only some ranks can see -- the base-case policies that factor on layer 0 or on the slice root alone
+// (policy.h:226-514) -- must unwind every rank or none: a rank that throws while its peers go on leaves them hanging in
+// their next collective.
+inline int ranks_with_nonzero(capi_comm_t comm, int word) {
+  int size = 1;
+  if (!comm || capi_comm_size(comm, &size) != CAPI_OK || size <= 1) return word != 0 ? 1 : 0;
+  double flag = word != 0 ? 1.0 : 0.0;
+  double* d = dev_alloc(1);
+  int rc = capi_memcpy_h2d(handle(), d, &flag, sizeof(double));
+  if (rc == CAPI_OK) rc = capi_allreduce_sum(comm, d, 1);
+  if (rc == CAPI_OK) rc = capi_memcpy_d2h(handle(), &flag, d, sizeof(double));
+  dev_free(d);
+  check(rc, "ranks_with_nonzero");
+  return (int)(flag + 0.5);
+}
+
 }  // namespace capital
 
 #endif  // CAPITAL_SHARED_H_

@@ -110,6 +110,26 @@ def main():
         p = driver.Cholinv(cfg["n"], c=cfg["c"], complete_inv=cfg["ci"], split=cfg.get("split", 1), bc_mult=cfg["bc"],
                            layout=cfg.get("layout", 0), num_chunks=cfg.get("chunks", 0), serialize=cfg["serialize"], bc_policy=cfg["policy"])
         p.generate()
+        if "spoil" in cfg:
+            # a non-SPD input: global diagonal element g made negative on the rank that owns it (local (i,j) <-> global (x + i d, y + j d))
+            g = cfg["spoil"]
+            if p.x == g % p.d and p.y == g % p.d:
+                Aloc = p.A()
+                Aloc[g // p.d, g // p.d] = -1.0
+                p.set_A(Aloc)
+            raised = ""
+            try:
+                p.factor()
+            except driver.DriverError as e:
+                raised = str(e)
+            # every rank must come back (no one left in a collective) and every rank must have been told
+            dist.barrier()
+            np.savez(os.path.join(cfg["dir"], f"rank{rank}.npz"), raised=np.array(raised), xyz=np.array([p.x, p.y, p.z, p.d, p.c]))
+            p.close()
+            lib.capital_drv_finalize()
+            dist.barrier()
+            dist.destroy_process_group()
+            return
         p.factor()
         res = p.residual()
         np.savez(os.path.join(cfg["dir"], f"rank{rank}.npz"), A=p.A(), R=p.R(), Rinv=p.Rinv(), xyz=np.array([p.x, p.y, p.z, p.d, p.c]),

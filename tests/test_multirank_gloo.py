@@ -93,6 +93,22 @@ def test_cholinv_on_grids(oracle, shim_lib, world, c, n, bc, ci, serialize, poli
         assert len(levels) == 1            # every rank walked the same recursion
 
 
+@pytest.mark.parametrize("world,c,policy,serialize", [(8, 2, 0, True), (8, 2, 1, False), (8, 2, 2, True), (8, 2, 3, False), (4, 1, 2, False), (2, 2, 1, True)])
+def test_non_spd_input_unwinds_every_rank(shim_lib, world, c, policy, serialize):
+    """Only the ranks that factor the aggregate see LAPACK's info (layer 0 with ReplicateComp, the slice root with NoReplication[Overlap],
+    policy.h:226-514).  The grid must agree before anyone throws: every rank raises, nobody is left waiting in a collective."""
+    with tempfile.TemporaryDirectory() as d:
+        _launch(world, {"kind": "cholinv", "n": 96, "c": c, "bc": -1, "ci": 1, "serialize": serialize, "policy": policy, "chunks": 0, "dir": d,
+                        "spoil": 61}, timeout=120)
+        saw_pivot = 0
+        for r in range(world):
+            z = np.load(os.path.join(d, f"rank{r}.npz"))
+            msg = str(z["raised"])
+            assert "not positive definite" in msg, (r, msg)
+            saw_pivot += "non-positive pivot" in msg
+        assert 1 <= saw_pivot <= world
+
+
 @pytest.mark.parametrize("world,c,layout", [(8, 2, 1), (8, 2, 2), (4, 1, 1)])
 def test_cholinv_rank_layouts(oracle, shim_lib, world, c, layout):
     """rank -> (x,y,z) layouts 1 and 2 of topo::square (topology.h:96-123): the grid positions change, the factor does not"""

@@ -167,6 +167,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-qr", action="store_true")
     ap.add_argument("--no-config2", action="store_true")
+    ap.add_argument("--qr-rows", type=int, default=0, help="override the rows per GPU of the config-5 slice (diagnostics / rehearsal only)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal only: all N ranks on GPU 0 (needs CAPI_RCCL_LIB = the loopback "
                     "library of tests/rccl_loopback; RCCL itself refuses two ranks on one device); never a measurement")
     args = ap.parse_args()
@@ -272,6 +273,8 @@ def main():
                              "algorithmic_GBps_per_gpu": 6 * 8.0 * m3 * n3 / (q3["ms"] * 1e-3) / 1e9,
                              "residual": q3["residual"], "orthogonality": q3["orthogonality"]}
         m_loc, n5 = QR_CONFIG5_SLICE
+        if args.qr_rows:
+            m_loc = args.qr_rows
         m5 = m_loc * args.gpus
         q5 = time_cacqr2(driver, m5, n5, reps, distributed, device)
         out["cacqr2_config5"] = {"workload": f"CA-CholeskyQR2 m={m5} n={n5} (1-D row blocks, {args.gpus} GPU; per-GPU slice {m_loc} x {n5} of BASELINE config 5"

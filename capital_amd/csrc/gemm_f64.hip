@@ -1709,6 +1709,12 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
       const size_t lds_bytes = sizeof(double) * 2 * (size_t)kcap * SLD;
       const int vi = (ak ? 2 : 0) + (bkc ? 1 : 0);
       CAPI_RAISE_LDS_LIMIT(h, CAPI_ATTR_SMALL0 + vi, k, sizeof(double) * 2 * SKC * SLD);
+      if (dbg) {
+        static long launch_no = 0;
+        fprintf(stderr, "[capi gemm]   small launch #%ld v=%d grid=(%d,%d) lds=%zu stream=%p A=%p lda=%ld B=%p ldb=%ld C=%p ldc=%ld batch=%d sa=%ld sb=%ld sc=%ld\n",
+                ++launch_no, vi, p.ntiles, p.batch > 1 ? p.batch : 1, lds_bytes, (void*)s, (const void*)p.A, (long)p.lda, (const void*)p.B, (long)p.ldb,
+                (void*)p.C, (long)p.ldc, p.batch, (long)p.sa, (long)p.sb, (long)p.sc);
+      }
       hipLaunchKernelGGL(k, dim3((unsigned)p.ntiles, (unsigned)(p.batch > 1 ? p.batch : 1)), dim3(256), lds_bytes, s, p);
       CAPI_HIP_CHECK(h, hipGetLastError());
       return CAPI_OK;

@@ -4,7 +4,11 @@ RCCL world communicator from a shipped unique id, topo::square / topo::rect spli
 depth all-reduces (summa.hpp:163-254), base-case gathers (policy.h:160-514), the partner exchange (util.hpp:232-247), the
 chunked pipeline on a second stream, the CQR2 Gram all-reduce (cacqr/policy.h:18-24).  The assembled factors must equal the
 1-rank oracle: R of an SPD matrix is unique.  Skips (per case) when the box has fewer GPUs than the case needs; the one-rank
-case runs everywhere and sends even a 1-rank communicator through RCCL (CAPI_RCCL_FORCE), so the script itself is always exercised."""
+case runs everywhere and sends even a 1-rank communicator through RCCL (CAPI_RCCL_FORCE), so the script itself is always exercised.
+
+The `loopback` cases run the same ranks, 2 (1x1x2) and 4 (2x2x1) of them, all on GPU 0, with tests/rccl_loopback standing in for
+librccl.so (RCCL proper refuses two ranks on one device): the product's kernels, packed wire formats, d > 1 base cases, K-class SUMMA
+and stream / event discipline then execute on a real MI355X on every 1-GPU box; only the transport is not RCCL's."""
 import json
 import os
 import socket
@@ -32,14 +36,19 @@ def _free_port():
     return p
 
 
-def _launch(world, cfg, timeout=900):
+LOOPBACK = os.path.join(HERE, "rccl_loopback", "librccl_loopback.so")
+
+
+def _launch(world, cfg, timeout=900, loopback=False):
     port = _free_port()
     procs = []
     for r in range(world):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0" if loopback else str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    GLOO_SOCKET_IFNAME="lo", HSA_ENABLE_IPC_MODE_LEGACY="0", CAPITAL_MIN_CHUNK_COLS="64")
         if world == 1:
             env["CAPI_RCCL_FORCE"] = "1"
+        if loopback:
+            env["CAPI_RCCL_LIB"] = LOOPBACK
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_gpu_rank_main.py"), json.dumps(cfg)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -58,9 +67,12 @@ def _launch(world, cfg, timeout=900):
 GRID_C = {1: 1, 2: 2, 4: 1, 8: 2}
 
 
-@pytest.mark.parametrize("world", [1, 2, 4, 8])
-def test_cholinv_and_cacqr2_on_rccl(oracle, world):
-    if _gpus() < world:
+@pytest.mark.parametrize("world,loopback", [(1, False), (2, False), (4, False), (8, False), (2, True), (4, True)],
+                         ids=["rccl1", "rccl2", "rccl4", "rccl8", "loopback2", "loopback4"])
+def test_cholinv_and_cacqr2_on_rccl(oracle, world, loopback):
+    if loopback:
+        subprocess.check_call(["make", "-C", os.path.dirname(LOOPBACK), "-s"])
+    elif _gpus() < world:
         pytest.skip(f"needs {world} GPUs, this box has {_gpus()}")
     c = GRID_C[world]
     n, m_loc, nq = 4096, 1 << 15, 256
@@ -76,7 +88,7 @@ def test_cholinv_and_cacqr2_on_rccl(oracle, world):
         cases.append({"tag": "qr3d", "kind": "cacqr", "m": 1 << 14, "n": 512, "c": 2, "ci": 1, "bc": -1, "serialize": False})
         cases.append({"tag": "ch_l1", "kind": "cholinv", "n": n, "c": c, "bc": -3, "ci": 1, "serialize": False, "policy": 0, "layout": 1})
     with tempfile.TemporaryDirectory() as d:
-        _launch(world, {"dir": d, "cases": cases})
+        _launch(world, {"dir": d, "cases": cases}, loopback=loopback)
         for case in cases:
             tag = case["tag"]
             if case["kind"] == "cholinv":

@@ -26,6 +26,8 @@ _SIGS = {
     "capi_dgemm": [_int, _int, _i64, _i64, _i64, _dbl, _vp, _i64, _vp, _i64, _dbl, _vp, _i64],
     "capi_dsyrk": [_int, _int, _i64, _i64, _dbl, _vp, _i64, _dbl, _vp, _i64],
     "capi_dgemmt": [_int, _int, _int, _i64, _i64, _dbl, _vp, _i64, _vp, _i64, _dbl, _vp, _i64],
+    "capi_dsyrk_panel32": [_i64, _i64, _dbl, _vp, _dbl, _vp, _i64],
+    "capi_dtrmm_right_panel32": [_i64, _i64, _dbl, _vp, _i64, _vp, _i64, _vp, _i64],
     "capi_dtrmm": [_int, _int, _int, _int, _i64, _i64, _dbl, _vp, _i64, _vp, _i64],
     "capi_dtrmm_oop": [_int, _int, _int, _int, _i64, _i64, _dbl, _vp, _i64, _vp, _i64, _vp, _i64],
     "capi_dtrmm_acc": [_int, _int, _int, _int, _i64, _i64, _dbl, _vp, _i64, _vp, _i64, _dbl, _vp, _i64],
@@ -84,6 +86,7 @@ _COMM_SIGS = {
     "capi_gather": [_vp, _vp, _vp, _i64, _int],
     "capi_scatter": [_vp, _vp, _vp, _i64, _int],
     "capi_comm_query": [_vp, C.POINTER(_int), C.POINTER(_int)],
+    "capi_pairs_transfer": [_vp, C.POINTER(_int), _vp, _vp, _i64, _vp],
 }
 
 _lib = None
@@ -122,6 +125,8 @@ def load():
     L.capi_comm_unique_id.argtypes = [_vp]
     L.capi_comm_init_rank.argtypes = [C.POINTER(_vp), _vp, _int, _vp, _int]
     L.capi_version.restype = _int
+    L.capi_pairs_scratch_count.argtypes = [_int, _i64]
+    L.capi_pairs_scratch_count.restype = _i64
     L.capi_device_count.restype = _int
     _lib = L
     return L

@@ -6,6 +6,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 #include "capi_internal.h"
+#include "pair_paths.h"
 
 struct capi_comm_s {
   ncclComm_t comm = nullptr;
@@ -274,6 +275,31 @@ int capi_sendrecv_replace(capi_comm_t c, double* buf, int64_t count, int peer, d
   if (rc != CAPI_OK) return rc;
   CAPI_HIP_CHECK(c->h, hipMemcpyAsync(buf, staging, sizeof(double) * count, hipMemcpyDeviceToDevice, c->h->stream));
   return CAPI_OK;
+}
+
+// Multi-path pair transfers (pair_paths.h): every rank of `c` -- the WORLD communicator of the node -- calls this with the same `dst`
+// array; rank r sends `count` doubles from its `send` to rank dst[r] (or nothing, dst[r] < 0), each rank receives from at most one.
+// Messages of at least CAPITAL_MULTIPATH_MIN (default 2^20) doubles are cut into size() units that travel over all links of the mesh
+// in two grouped rounds of ncclSend / ncclRecv, relayed through `scratch` (capi_pairs_scratch_count doubles) on the ranks in between;
+// shorter ones go directly.  Stream-ordered on the handle's selected stream like every other collective here.
+int64_t capi_pairs_scratch_count(int nranks, int64_t count) { return pair_paths::scratch_count(nranks, count); }
+
+int capi_pairs_transfer(capi_comm_t c, const int* dst, const double* send, double* recv, int64_t count, double* scratch) {
+  if (!c || !dst || count < 0) return CAPI_EINVAL;
+  struct RcclPaths {
+    capi_comm_t c;
+    ncclResult_t first = ncclSuccess;
+    int group_begin() { first = ncclSuccess; return g_rccl.GroupStart() == ncclSuccess ? 0 : CAPI_ECOMM; }
+    void send(const double* p, int64_t n, int peer) { NCCL_IN_GROUP(c, first, g_rccl.Send(p, (size_t)n, ncclDouble, peer, c->comm, c->h->stream)); }
+    void recv(double* p, int64_t n, int peer) { NCCL_IN_GROUP(c, first, g_rccl.Recv(p, (size_t)n, ncclDouble, peer, c->comm, c->h->stream)); }
+    int group_end() { return group_result(c, first, "capi_pairs_transfer"); }
+  };
+  if (!c->comm) return (c->size == 1 && dst[0] < 0) ? CAPI_OK : CAPI_EINVAL;     // a lone rank has nobody to send to
+  static const int64_t min_count = getenv("CAPITAL_MULTIPATH_MIN") ? atoll(getenv("CAPITAL_MULTIPATH_MIN")) : ((int64_t)1 << 20);
+  RcclPaths x{c};
+  const int rc = pair_paths::transfer(x, c->rank, c->size, dst, send, recv, count, scratch, min_count);
+  if (rc < 0) { snprintf(c->h->err, sizeof(c->h->err), "capi_pairs_transfer: invalid transfer set, or scratch missing"); return CAPI_EINVAL; }
+  return rc;
 }
 
 }  // extern "C"

@@ -96,6 +96,8 @@ struct GemmArgs {
   int tri_block;
   int pid_base;       // this launch covers pids [pid_base, pid_base + gridDim.x) of the tile enumeration (launch in resident rounds)
   int order;          // bit 0: a triangular output's tiles run in bands of 8 tile rows (tile_of_dims)
+  int a_tiled, c_tiled;   // tall-skinny kernels (n == 256): the tall operand / the output is a "panel32" image -- tiles of 32 rows x 256 columns,
+                      // each column-major with ld 32, tile t at 32 * 256 * t: every pass over the panel is ONE contiguous stream
 };
 
 // ---- global -> registers: this thread's 4 x 16 bytes of a 128 x 16 operand panel -----------------
@@ -1074,6 +1076,9 @@ __device__ __forceinline__ void gram_ts_body(const GemmArgs& p, double* __restri
   for (int q = 0; q < 17; ++q) acc[q] = (d4_t){0.0, 0.0, 0.0, 0.0};
 
   const int kp = tid & 7, c0 = tid >> 3;                   // this thread's pieces: columns c0 + 64 q, k = 2 kp (+1)
+  // operand addressing: column-major (k + c lda) or panel32 (32-row tiles: a 16-deep panel is half a tile)
+  const int64_t acs = p.a_tiled ? 32 : p.lda;              // column stride
+  auto poff = [&](int pnl) -> int64_t { return p.a_tiled ? (int64_t)(pnl >> 1) * (32 * TSK_W) + (pnl & 1) * 16 : (int64_t)pnl * BK; };
   // load() only ISSUES the loads (unconditional, from a clamped address); every select on their results waits until
   // stage(), after the MFMA phase -- a select right behind the load would make the wave wait for the prefetch up front
   auto load = [&](int pnl, d2_t (&st)[4]) {
@@ -1082,7 +1087,7 @@ __device__ __forceinline__ void gram_ts_body(const GemmArgs& p, double* __restri
     for (int q = 0; q < 4; ++q) {
       const int c = c0 + 64 * q;
       const bool in = c < N && k + 1 < p.K && p.a_vec;
-      st[q] = *(const d2_t*)(in ? p.A + (int64_t)c * p.lda + k : p.A);
+      st[q] = *(const d2_t*)(in ? p.A + (int64_t)c * acs + poff(pnl) + 2 * kp : p.A);
     }
   };
   auto stage = [&](double* L, int pnl, const d2_t (&st)[4]) {
@@ -1101,7 +1106,7 @@ __device__ __forceinline__ void gram_ts_body(const GemmArgs& p, double* __restri
       if (!in) {                                            // ragged edge / unaligned operand: scalar reads, rare
         v = (d2_t){0.0, 0.0};
         if (c < N) {
-          const double* ptr = p.A + (int64_t)c * p.lda + k;
+          const double* ptr = p.A + (int64_t)c * acs + poff(pnl) + 2 * kp;
           if (k < p.K) v.x = ptr[0];
           if (k + 1 < p.K) v.y = ptr[1];
         }
@@ -1121,9 +1126,9 @@ __device__ __forceinline__ void gram_ts_body(const GemmArgs& p, double* __restri
     constexpr bool STEADY = decltype(steady_tag)::value;
     const double* L = lds + par * STAGE;
     if (STEADY) {
-      const double* src = p.A + (int64_t)c0 * p.lda + pidx(it + 2) * BK + 2 * kp;
+      const double* src = p.A + (int64_t)c0 * acs + poff(pidx(it + 2)) + 2 * kp;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) nw[q] = TS_LOAD((const d2_t*)(src + (int64_t)(64 * q) * p.lda));
+      for (int q = 0; q < 4; ++q) nw[q] = TS_LOAD((const d2_t*)(src + (int64_t)(64 * q) * acs));
     } else if (it + 2 < np) load(pidx(it + 2), nw);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -1374,11 +1379,14 @@ __device__ __forceinline__ void trmm_ts32_body(const GemmArgs& p, double* __rest
 
   // thread t owns rows 2 (t & 15), +1 of columns (t >> 4) + 32 q: 16 lanes fetch the tile's 256 bytes of one column
   const int lc = tid >> 4, lr = 2 * (tid & 15);
+  // operand / output addressing: column-major (row + col ld) or panel32 (tile t at 32 * 256 * t, column stride 32)
+  const int64_t acs = p.a_tiled ? 32 : p.lda, ats = p.a_tiled ? 32 * 256 : 32;     // A: column stride, tile stride
+  const int64_t ccs = p.c_tiled ? 32 : p.ldc, cts = p.c_tiled ? 32 * 256 : 32;     // C likewise
   const int lofs = (lr >> 4) * HALF + lc * 16 + (lr & 15);  // LDS offset of (rows lr, lr + 1; column lc)
   auto load = [&](int tile, d2_t (&st)[8]) {
     const bool in = 32 * tile + 32 <= p.M && p.a_vec;
-    const double* src = in ? p.A + 32 * tile + lr + (int64_t)lc * p.lda : p.A;
-    const int64_t cs = in ? 32 * p.lda : 0;
+    const double* src = in ? p.A + ats * tile + lr + (int64_t)lc * acs : p.A;
+    const int64_t cs = in ? 32 * acs : 0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) st[q] = *(const d2_t*)(src + q * cs);
   };
@@ -1393,8 +1401,8 @@ __device__ __forceinline__ void trmm_ts32_body(const GemmArgs& p, double* __rest
     for (int q = 0; q < 8; ++q) {                           // ragged last tile / unaligned A: scalar reads
       const int64_t c = lc + 32 * q;
       d2_t v = {0.0, 0.0};
-      if (r < p.M) v.x = p.A[r + c * p.lda];
-      if (r + 1 < p.M) v.y = p.A[r + 1 + c * p.lda];
+      if (r < p.M) v.x = p.A[ats * tile + lr + c * acs];
+      if (r + 1 < p.M) v.y = p.A[ats * tile + lr + 1 + c * acs];
       *(d2_t*)&L[lofs + 512 * q] = v;
     }
   };
@@ -1408,9 +1416,9 @@ __device__ __forceinline__ void trmm_ts32_body(const GemmArgs& p, double* __rest
     constexpr bool STEADY = decltype(steady_tag)::value;
     const double* L = lds + par * TILE;
     if (STEADY) {
-      const double* src = p.A + 32 * (tile + dt) + lr + (int64_t)lc * p.lda;
+      const double* src = p.A + ats * (tile + dt) + lr + (int64_t)lc * acs;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) st[q] = TS_LOAD((const d2_t*)(src + q * 32 * p.lda));
+      for (int q = 0; q < 8; ++q) st[q] = TS_LOAD((const d2_t*)(src + q * 32 * acs));
     } else if (tile + dt < ntile) load(tile + dt, st);
     d4_t ca0 = {0.0, 0.0, 0.0, 0.0}, ca1 = ca0, cb0 = ca0, cb1 = ca0;
     const double* la = L + g * 16 + r16;                    // A[row r16 (+16)][k = 4 s + g]
@@ -1435,9 +1443,9 @@ __device__ __forceinline__ void trmm_ts32_body(const GemmArgs& p, double* __rest
     __syncthreads();
     // lane holds (i = row r16 (+16) of the tile, j = 16 strip + g + 4 reg): 16 lanes -> 128 contiguous bytes of one column
     const int i = 32 * tile + r16;
-    double* c0_ = p.C + i + (int64_t)(16 * SA + g) * p.ldc;
-    double* c1_ = p.C + i + (int64_t)(16 * SB + g) * p.ldc;
-    const int64_t s4 = 4 * p.ldc;
+    double* c0_ = p.C + cts * tile + r16 + (int64_t)(16 * SA + g) * ccs;
+    double* c1_ = p.C + cts * tile + r16 + (int64_t)(16 * SB + g) * ccs;
+    const int64_t s4 = 4 * ccs;
     if (STEADY) {
       // 16-byte stores: lanes 2k and 2k+1 hold rows 2k, 2k+1 of the same columns, so a pair of registers (columns a, b) is
       // traded across the lane pair -- the even lane ends with rows 2k, 2k+1 of column a, the odd lane with those of column b.
@@ -1789,8 +1797,10 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
     rec = &h->prof[h->prof_n++];
     if (!rec->e0) { CAPI_HIP_CHECK(h, hipEventCreate(&rec->e0)); CAPI_HIP_CHECK(h, hipEventCreate(&rec->e1)); }
     // algorithmic flops of the whole product: gemm 2MNK, triangular output N(N+1)K, trmm M^2 N / M N^2
+    // (a tri_block launch is one 256-column block of a tall right-TRMM: a dense product above T's diagonal block plus that block's triangle)
     rec->flops = p.out_uplo >= 0 ? (double)p.N * ((double)p.N + 1.0) * (double)p.K
-                 : (p.tri_side >= 0 ? (double)p.M * (double)p.N * (double)p.K : 2.0 * (double)p.M * (double)p.N * (double)p.K);
+                 : (p.tri_side >= 0 ? (p.tri_block ? (double)p.M * (double)p.N * (2.0 * (double)p.tri_koff + (double)p.N) : (double)p.M * (double)p.N * (double)p.K)
+                                    : 2.0 * (double)p.M * (double)p.N * (double)p.K);
     rec->flops *= share;
     rec->variant = (ak ? 2 : 0) + (bkc ? 1 : 0) + (p.ts == 128 ? 0 : 4);
     rec->m = p.M; rec->n = p.N; rec->k = p.K; rec->kind = p.out_uplo >= 0 ? 1 : (p.tri_side >= 0 ? 2 : 0);
@@ -1983,6 +1993,10 @@ static int trmm_launch(capi_handle_t h, int side, int uplo, int trans, int diag,
     // column tiles of a row tile consecutive arrivals was measured slower (152.7 ms).  (CAPI_TALL_ONE_LAUNCH: A/B.)
     static const bool one_launch = getenv("CAPI_TALL_ONE_LAUNCH") != nullptr;
     const bool eff_upper = (uplo == CAPI_UPPER) != (trans == CAPI_TRANS);
+    // (Round 3, measured and dropped: each block's diagonal 256 x 256 part by the T-stationary kernel -- exactly the 136 live MFMA tiles,
+    //  B_J read once -- and the part above it as a dense beta = 1 product on the tile kernel: 16.25 instead of 18 executed units of
+    //  m * 65536 flops at n = 1024, yet 36.1 against 35.3 ms at m = 2^21 (n = 512: 10.4 against 9.8): the accumulating products have
+    //  K = 256 .. 768 only, and a 128-tile with 16-48 iterations spends too much of its life in prologue, C read and epilogue.)
     if (!one_launch && eff_upper && n % 256 == 0) {
       for (int64_t J = 0; J < n / 256; ++J) {
         GemmArgs q = p;
@@ -2059,6 +2073,39 @@ int capi_dtrmm(capi_handle_t h, int side, int uplo, int trans, int diag, int64_t
   CAPI_HIP_CHECK(h, hipMemcpy2DAsync(B, sizeof(double) * ldb, ws, sizeof(double) * m, sizeof(double) * m, n,
                                      hipMemcpyDeviceToDevice, h->stream));
   return CAPI_OK;
+}
+
+// ---- "panel32" images of a tall panel (CholeskyQR2, n = 256) -------------------------------------------------------------------------------
+// An m x 256 panel (m % 32 == 0) stored as m / 32 tiles of 32 rows, each tile column-major with ld 32, tile t at 32 * 256 * t doubles:
+// element (i, j) sits at (i / 32) * 8192 + 32 j + i % 32.  A column-major tall panel is 256 column streams 8 lda bytes apart, touched
+// 256 bytes at a time; a panel32 image is ONE contiguous stream.  qr::cacqr keeps the intermediate Q1 of CholeskyQR2 (written by sweep 1,
+// read twice by sweep 2, never seen by the caller) in this form: three of the six passes over the panel become contiguous.
+int capi_dsyrk_panel32(capi_handle_t h, int64_t n, int64_t k, double alpha, const double* A32, double beta, double* C, int64_t ldc) {
+  CAPI_REQUIRE(h, h, "null handle");
+  CAPI_REQUIRE(h, n == TSK_W && k > 0 && k % 32 == 0 && k >= 64 * n && k < (1LL << 31), "panel32 Gram matrix: n == 256, k a multiple of 32, k >= 64 n");
+  CAPI_REQUIRE(h, A32 && C && ldc >= n && (((uintptr_t)A32 & 15) == 0), "operands");
+  CAPI_REQUIRE(h, getenv("CAPI_NO_TS") == nullptr, "panel32 images need the full-width tall-skinny kernels (CAPI_NO_TS is set)");
+  GemmArgs p{};
+  p.A = A32; p.B = A32; p.C = C; p.lda = 32; p.ldb = 32; p.ldc = ldc;
+  p.M = (int)n; p.N = (int)n; p.K = (int)k; p.alpha = alpha; p.beta = beta;
+  p.out_uplo = CAPI_UPPER; p.tri_side = -1;
+  p.a_tiled = 1;
+  return launch_gemm(h, true, true, p, true);
+}
+
+// C = alpha * B * T, T 256 x 256 upper triangular (non-unit), B and C m x 256; ldb == 0: B is a panel32 image, ldc == 0: C is written as one
+int capi_dtrmm_right_panel32(capi_handle_t h, int64_t m, int64_t n, double alpha, const double* T, int64_t ldt, const double* B, int64_t ldb,
+                             double* C, int64_t ldc) {
+  CAPI_REQUIRE(h, h, "null handle");
+  CAPI_REQUIRE(h, n == TSK_W && m > 0 && m % 32 == 0 && m >= 64 * n && m < (1LL << 31), "panel32 right-TRMM: n == 256, m a multiple of 32, m >= 64 n");
+  CAPI_REQUIRE(h, T && B && C && ldt >= n && (ldb == 0 || ldb >= m) && (ldc == 0 || ldc >= m) && (const double*)C != B, "operands");
+  CAPI_REQUIRE(h, getenv("CAPI_NO_TS") == nullptr && getenv("CAPI_TS_ROWS16") == nullptr, "panel32 images need the 32-row T-stationary kernel");
+  GemmArgs p{};
+  p.C = C; p.ldc = ldc ? ldc : 32; p.M = (int)m; p.N = (int)n; p.K = (int)n; p.alpha = alpha; p.beta = 0.0;
+  p.out_uplo = -1; p.tri_side = CAPI_RIGHT; p.tri_eff_upper = 1; p.tri_unit = 0;
+  p.A = B; p.lda = ldb ? ldb : 32; p.B = T; p.ldb = ldt;
+  p.a_tiled = ldb == 0; p.c_tiled = ldc == 0;
+  return launch_gemm(h, false, true, p, true);
 }
 
 int capi_prof_enable(capi_handle_t h, int on) {

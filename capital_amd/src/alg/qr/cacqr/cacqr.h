@@ -85,11 +85,14 @@ public:
 
 protected:
   // one CholeskyQR sweep: dst <- src * chol(src^T src)^-1 ; leaves R in args.G and R^-1 in args.Ginv
+  // src_tiled / dst_tiled: the panel is a "panel32" image (include/capital_hip.h) instead of column-major -- CholeskyQR2's intermediate Q1
   template <typename ArgType, typename CommType>
-  static void sweep_1d(const double* src, double* dst, int64_t m_loc, int64_t n, ArgType& args, CommType&& CommInfo) {
+  static void sweep_1d(const double* src, double* dst, int64_t m_loc, int64_t n, ArgType& args, CommType&& CommInfo, bool src_tiled = false,
+                       bool dst_tiled = false) {
     capi_handle_t h = capital::handle();
     CRITTER_START(CQR::gram);
-    CAPITAL_CHECK(capi_dsyrk(h, CAPI_UPPER, CAPI_TRANS, n, m_loc, 1.0, src, m_loc, 0.0, args.G.data(), n));           // K7
+    if (src_tiled) CAPITAL_CHECK(capi_dsyrk_panel32(h, n, m_loc, 1.0, src, 0.0, args.G.data(), n));                  // K7 on the image
+    else CAPITAL_CHECK(capi_dsyrk(h, CAPI_UPPER, CAPI_TRANS, n, m_loc, 1.0, src, m_loc, 0.0, args.G.data(), n));      // K7
     if (CommInfo.size > 1) {                                                                                       // C8
       if (SP::packed_gram) {
         serialize<uppertri, uppertri>::invoke(args.G, args.Gpacked, 0, n, 0, n, 0, n, 0, n);
@@ -102,7 +105,10 @@ protected:
     CRITTER_STOP(CQR::gram);
     CRITTER_START(CQR::formR);
     CAPITAL_CHECK(capi_dpotrf_trtri(h, n, args.G.data(), n, args.Ginv.data(), n));                                    // K8 + K9
-    CAPITAL_CHECK(capi_dtrmm_oop(h, CAPI_RIGHT, CAPI_UPPER, CAPI_NOTRANS, CAPI_NONUNIT, m_loc, n, 1.0, args.Ginv.data(), n, src, m_loc, dst, m_loc));  // K5
+    if (src_tiled || dst_tiled)
+      CAPITAL_CHECK(capi_dtrmm_right_panel32(h, m_loc, n, 1.0, args.Ginv.data(), n, src, src_tiled ? 0 : m_loc, dst, dst_tiled ? 0 : m_loc));       // K5
+    else
+      CAPITAL_CHECK(capi_dtrmm_oop(h, CAPI_RIGHT, CAPI_UPPER, CAPI_NOTRANS, CAPI_NONUNIT, m_loc, n, 1.0, args.Ginv.data(), n, src, m_loc, dst, m_loc));  // K5
     CRITTER_STOP(CQR::formR);
   }
 
@@ -115,11 +121,16 @@ protected:
     if (SP::packed_gram) args.Gpacked._register_(n, n, 1, 1);
     CAPITAL_CHECK(capi_reset_info(h));
     args.potrf_info = 0;
-    sweep_1d(A.data(), args.Q.data(), m_loc, n, args, CommInfo);
+    // CholeskyQR2 at the full-width kernels' shape (n = 256, tall, whole 32-row tiles): Q1 = A R1^-1 is never seen by the caller; it is
+    // written by sweep 1 and read twice by sweep 2 as a panel32 image -- one contiguous stream per pass instead of 256 column streams
+    // (CAPITAL_NO_PANEL32: column-major throughout, A/B).  The arithmetic, and so Q and R, are the same bit for bit.
+    const bool q1_tiled = args.num_iter > 1 && n == 256 && m_loc % 32 == 0 && m_loc >= 64 * n && !getenv("CAPITAL_NO_PANEL32") &&
+                          !getenv("CAPI_NO_TS") && !getenv("CAPI_TS_ROWS16");
+    sweep_1d(A.data(), args.Q.data(), m_loc, n, args, CommInfo, false, q1_tiled);
     if (args.num_iter > 1) {
       args.R1._register_(n, n, 1, 1);
       capital::dev_copy(args.R1.data(), args.G.data(), n * n);                                                        // save_R_1d
-      sweep_1d(args.Q.data(), args.Q.scratch(), m_loc, n, args, CommInfo);
+      sweep_1d(args.Q.data(), args.Q.scratch(), m_loc, n, args, CommInfo, q1_tiled, false);
       args.Q.swap();
       // R = R2 * R1 (cacqr.hpp:185-187): Ginv is free again and receives the product
       CAPITAL_CHECK(capi_dtrmm_oop(h, CAPI_RIGHT, CAPI_UPPER, CAPI_NOTRANS, CAPI_NONUNIT, n, n, 1.0, args.R1.data(), n, args.G.data(), n, args.Ginv.data(), n));

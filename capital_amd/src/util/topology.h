@@ -58,6 +58,11 @@ public:
     slice = detail::split(comm, (int)z, (int)(x + d * y));              // same z; slice rank = x + d*y
     row = detail::split(slice, (int)y, (int)x);                         // same y (and z), ordered by x
     column = detail::split(slice, (int)x, (int)y);                      // same x (and z), ordered by y
+    // Multi-path pair transfers (capi_pairs_transfer): on a grid whose rows / columns (d == 2) or depth fibres (c == 2) are PAIRS,
+    // the pair collectives of SUMMA are issued by ALL ranks of `comm` together and cut over every link of the node's mesh instead
+    // of one link per pair.  Needs ranks that can relay (size >= 4).  CAPITAL_MULTIPATH=0 keeps the per-pair RCCL calls.
+    const char* mp = getenv("CAPITAL_MULTIPATH");
+    multipath = size >= 4 && (d == 2 || c == 2) && !(mp && atoi(mp) == 0);
   }
   square(const square&) = delete;
   square& operator=(const square&) = delete;
@@ -95,9 +100,48 @@ public:
     return -1;
   }
 
+  // ---- transfer sets for capi_pairs_transfer: dst[r] for every rank r of `world` (identical on all ranks) ------------------------
+  enum axis_t { AX_ROW = 0, AX_COLUMN = 1 };
+  bool pairs_along(int axis) const { (void)axis; return multipath && d == 2; }        // rows and columns of two
+  bool pairs_in_depth() const { return multipath && c == 2; }
+  // broadcast inside every row (column) from the member whose x (y) equals the K-class of its layer at step s, q = z + s c
+  // (summa.hpp:185,193: the roots of the reference are x == z and y == z)
+  std::vector<int> bcast_dst(int axis, size_t s) const {
+    std::vector<int> dst((size_t)size, -1);
+    for (int r = 0; r < size; ++r) {
+      size_t px, py, pz;
+      coords(r, px, py, pz);
+      const size_t q = pz + s * c;
+      if ((axis == AX_ROW ? px : py) != q) continue;
+      dst[(size_t)r] = axis == AX_ROW ? rank_of(1 - px, py, pz) : rank_of(px, 1 - py, pz);
+    }
+    return dst;
+  }
+  // every rank sends to the other member of its depth fibre (the two halves of MPI_Allreduce, summa.hpp:236)
+  std::vector<int> depth_dst() const {
+    std::vector<int> dst((size_t)size, -1);
+    for (int r = 0; r < size; ++r) {
+      size_t px, py, pz;
+      coords(r, px, py, pz);
+      dst[(size_t)r] = rank_of(px, py, 1 - pz);
+    }
+    return dst;
+  }
+  // every off-diagonal rank sends to its transpose partner (y, x, z) (util.hpp:237-240)
+  std::vector<int> transpose_dst() const {
+    std::vector<int> dst((size_t)size, -1);
+    for (int r = 0; r < size; ++r) {
+      size_t px, py, pz;
+      coords(r, px, py, pz);
+      if (px != py) dst[(size_t)r] = rank_of(py, px, pz);
+    }
+    return dst;
+  }
+
   capi_comm_t world = nullptr, row = nullptr, column = nullptr, slice = nullptr, depth = nullptr;
   int rank = 0, size = 1;
   size_t c = 1, d = 1, x = 0, y = 0, z = 0, layout = 0, num_chunks = 0;
+  bool multipath = false;
 };
 
 class rect {

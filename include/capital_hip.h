@@ -92,6 +92,14 @@ int capi_dtrsm(capi_handle_t h, int side, int uplo, int trans, int diag, int64_t
 
 /* ---- LAPACK layer: replaces lapack::engine::_potrf/_trtri (src/lapack/interface.h:49-53,
  *      src/lapack/interface.hpp:30-58 -> LAPACKE_dpotrf/dtrtri, column-major) ---- */
+/* "panel32" images of a tall m x 256 panel (m % 32 == 0): m / 32 tiles of 32 rows, each tile column-major with ld 32, tile t at
+ * 8192 t doubles -- element (i, j) at (i / 32) * 8192 + 32 j + i % 32.  One contiguous stream per pass instead of 256 column streams.
+ * qr::cacqr (cacqr.hpp:174-193) keeps CholeskyQR2's intermediate Q1 = A R1^-1 in this form between its two sweeps (K7 / K5 of SURVEY 2.2 on
+ * that image): capi_dsyrk_panel32: C(upper) = alpha A^T A + beta C, A a panel32 image of k x 256 (k >= 64 * 256);
+ * capi_dtrmm_right_panel32: C = alpha B T, T 256 x 256 upper, non-unit; ldb == 0 / ldc == 0 mark B / C as panel32 images. */
+int capi_dsyrk_panel32(capi_handle_t h, int64_t n, int64_t k, double alpha, const double* A32, double beta, double* C, int64_t ldc);
+int capi_dtrmm_right_panel32(capi_handle_t h, int64_t m, int64_t n, double alpha, const double* T, int64_t ldt,
+                             const double* B, int64_t ldb, double* C, int64_t ldc);
 /* The LAPACK `info` the reference discards is kept on the device; capi_get_info() synchronises and
  * returns it (0, or 1-based index of the first non-positive pivot / zero diagonal). */
 int capi_dpotrf(capi_handle_t h, int uplo, int64_t n, double* A, int64_t lda);
@@ -170,6 +178,15 @@ int capi_allreduce_sum(capi_comm_t c, double* buf, int64_t count);              
 int capi_reduce_sum(capi_comm_t c, const double* send, double* recv, int64_t count, int root);  /* MPI_Reduce, cacqr.hpp:98 */
 int capi_allgather(capi_comm_t c, const double* send, double* recv, int64_t count_per_rank);   /* MPI_Allgather, policy.h:176 */
 int capi_sendrecv_replace(capi_comm_t c, double* buf, int64_t count, int peer, double* staging); /* MPI_Sendrecv_replace, util.hpp:240 */
+/* Grid-wide set of pair transfers over ALL xGMI links of the node (csrc/pair_paths.h).  The pair collectives of the 3-D SUMMA on a
+ * 2 x 2 x 2 grid -- MPI_Bcast over a row / column of two (summa.hpp:185,193), the halves of MPI_Allreduce over a depth fibre of two
+ * (summa.hpp:236), MPI_Sendrecv_replace with the transpose partner (util.hpp:240) -- each move 1-2 GiB between two GPUs; as calls on
+ * 2-rank communicators they use one of the sender's seven links.  Here every rank of `world` calls with the SAME dst[0..size): rank r
+ * sends `count` doubles from `send` to rank dst[r] (dst[r] < 0: sends nothing); a rank is the destination of at most one transfer and
+ * receives into `recv`.  Long messages are cut into `size` units: two travel directly, the others are relayed by the remaining ranks
+ * (two grouped rounds of ncclSend/ncclRecv) through `scratch`, capi_pairs_scratch_count(size, count) doubles on every rank. */
+int64_t capi_pairs_scratch_count(int nranks, int64_t count);
+int capi_pairs_transfer(capi_comm_t world, const int* dst, const double* send, double* recv, int64_t count, double* scratch);
 /* root collects / deals `count_per_rank` doubles per rank, rank r's piece at recv/send + r*count (one group of RCCL send/recv) */
 int capi_gather(capi_comm_t c, const double* send, double* recv, int64_t count_per_rank, int root);   /* MPI_Gather, cholinv/policy.h:322-332 */
 int capi_scatter(capi_comm_t c, const double* send, double* recv, int64_t count_per_rank, int root);  /* MPI_Scatter / MPI_Iscatter, policy.h:361-377,470-488 */

@@ -15,6 +15,7 @@
 
 #include "capital_hip.h"
 #include "../../oracle/capital_oracle.h"
+#include "../../capital_amd/csrc/pair_paths.h"
 
 struct capi_handle_s { char err[256]; int info; };
 struct capi_comm_s { std::vector<int> ranks; int me; capi_handle_t h; };
@@ -82,6 +83,32 @@ int capi_dtrmm_acc(capi_handle_t, int side, int uplo, int trans, int diag, int64
 int capi_dtrmm_oop(capi_handle_t h, int side, int uplo, int trans, int diag, int64_t m, int64_t n, double alpha, const double* T,
                    int64_t ldt, const double* B, int64_t ldb, double* C, int64_t ldc) {
   return capi_dtrmm_acc(h, side, uplo, trans, diag, m, n, alpha, T, ldt, B, ldb, 0.0, C, ldc);
+}
+// panel32 images (include/capital_hip.h): un-tile / re-tile around the column-major routines
+static void from_panel32(const double* src, int64_t m, int64_t n, double* dst) {
+  for (int64_t j = 0; j < n; ++j)
+    for (int64_t i = 0; i < m; ++i) dst[i + j * m] = src[(i / 32) * 32 * n + 32 * j + i % 32];
+}
+static void to_panel32(const double* src, int64_t m, int64_t n, double* dst) {
+  for (int64_t j = 0; j < n; ++j)
+    for (int64_t i = 0; i < m; ++i) dst[(i / 32) * 32 * n + 32 * j + i % 32] = src[i + j * m];
+}
+int capi_dsyrk_panel32(capi_handle_t h, int64_t n, int64_t k, double alpha, const double* A32, double beta, double* C, int64_t ldc) {
+  if (n != 256 || k % 32 || k < 64 * n) return CAPI_EINVAL;
+  std::vector<double> W((size_t)k * n);
+  from_panel32(A32, k, n, W.data());
+  return capi_dsyrk(h, CAPI_UPPER, CAPI_TRANS, n, k, alpha, W.data(), k, beta, C, ldc);
+}
+int capi_dtrmm_right_panel32(capi_handle_t h, int64_t m, int64_t n, double alpha, const double* T, int64_t ldt, const double* B, int64_t ldb,
+                             double* C, int64_t ldc) {
+  if (n != 256 || m % 32 || m < 64 * n) return CAPI_EINVAL;
+  std::vector<double> Bc, Cc;
+  if (ldb == 0) { Bc.resize((size_t)m * n); from_panel32(B, m, n, Bc.data()); B = Bc.data(); ldb = m; }
+  if (ldc != 0) return capi_dtrmm_oop(h, CAPI_RIGHT, CAPI_UPPER, CAPI_NOTRANS, CAPI_NONUNIT, m, n, alpha, T, ldt, B, ldb, C, ldc);
+  Cc.resize((size_t)m * n);
+  int rc = capi_dtrmm_oop(h, CAPI_RIGHT, CAPI_UPPER, CAPI_NOTRANS, CAPI_NONUNIT, m, n, alpha, T, ldt, B, ldb, Cc.data(), m);
+  to_panel32(Cc.data(), m, n, C);
+  return rc;
 }
 int capi_dtrsm(capi_handle_t, int side, int uplo, int trans, int diag, int64_t m, int64_t n, double alpha, const double* T,
                int64_t ldt, double* B, int64_t ldb) {
@@ -275,6 +302,30 @@ int capi_scatter(capi_comm_t c, const double* send, double* recv, int64_t count,
   if (coll(c, 0, all.data(), nullptr, (int64_t)all.size(), root)) return CAPI_ECOMM;
   memcpy(recv, all.data() + (size_t)c->me * count, sizeof(double) * count);
   return 0;
+}
+// multi-path pair transfers: the product's own algorithm (capital_amd/csrc/pair_paths.h) over the callback's grouped point-to-point op
+//   op 5: buf = array of p2p_entry, count = entries; every entry is posted (isend / irecv) before any is awaited -- one RCCL group
+struct p2p_entry { double* ptr; int64_t count; int32_t peer_world; int32_t is_send; };
+int64_t capi_pairs_scratch_count(int nranks, int64_t count) { return pair_paths::scratch_count(nranks, count); }
+int capi_pairs_transfer(capi_comm_t c, const int* dst, const double* send, double* recv, int64_t count, double* scratch) {
+  if (!c || !dst || count < 0) return CAPI_EINVAL;
+  struct ShimPaths {
+    capi_comm_t c;
+    std::vector<p2p_entry> posted;
+    int group_begin() { posted.clear(); return 0; }
+    void send(const double* p, int64_t n, int peer) { posted.push_back({(double*)p, n, c->ranks[(size_t)peer], 1}); }
+    void recv(double* p, int64_t n, int peer) { posted.push_back({p, n, c->ranks[(size_t)peer], 0}); }
+    int group_end() {
+      if (posted.empty()) return 0;
+      if (!g_cb) return CAPI_ECOMM;
+      return g_cb(5, c->ranks.data(), (int)c->ranks.size(), c->me, (double*)posted.data(), nullptr, (int64_t)posted.size(), 0) ? CAPI_ECOMM : 0;
+    }
+  };
+  if (c->ranks.size() == 1) return dst[0] < 0 ? 0 : CAPI_EINVAL;
+  const int64_t min_count = getenv("CAPITAL_MULTIPATH_MIN") ? atoll(getenv("CAPITAL_MULTIPATH_MIN")) : ((int64_t)1 << 20);
+  ShimPaths x{c, {}};
+  const int rc = pair_paths::transfer(x, c->me, (int)c->ranks.size(), dst, send, recv, count, scratch, min_count);
+  return rc < 0 ? CAPI_EINVAL : rc;
 }
 int capi_comm_query(capi_comm_t c, int* r, int* s) { if (!c) return CAPI_EINVAL; *r = c->me; *s = (int)c->ranks.size(); return 0; }
 int capi_trim_workspaces(capi_handle_t) { return 0; }

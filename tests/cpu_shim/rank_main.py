@@ -84,6 +84,22 @@ def make_callback():
                 else:
                     dist.recv(t, peer)
                     dist.send(snd, peer)
+            elif op == 5:    # one group of point-to-point messages (capi_pairs_transfer): post everything, then wait
+                class Entry(C.Structure):
+                    _fields_ = [("ptr", C.c_void_p), ("count", C.c_int64), ("peer", C.c_int32), ("is_send", C.c_int32)]
+                ents = C.cast(buf, C.POINTER(Entry))
+                reqs, keep_alive = [], []
+                for i in range(count):
+                    e = ents[i]
+                    t = view(e.ptr, e.count)
+                    if e.is_send:
+                        t = t.clone()           # (the group's sends read their buffers at posting time, as a stream-ordered send does)
+                        keep_alive.append(t)
+                        reqs.append(dist.isend(t, e.peer))
+                    else:
+                        reqs.append(dist.irecv(t, e.peer))
+                for r in reqs:
+                    r.wait()
             else:
                 return 1
             return 0

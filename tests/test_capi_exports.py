@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     # every function the Python binding uses is declared in the header (no private back doors)
     bound = set(capi._SIGS) | set(capi._COMM_SIGS) | {"capi_create", "capi_create_on_stream", "capi_destroy", "capi_get_stream",
                                                     "capi_last_error", "capi_comm_load_rccl", "capi_comm_unique_id",
-                                                    "capi_comm_init_rank", "capi_version", "capi_device_count"}
+                                                    "capi_comm_init_rank", "capi_version", "capi_device_count", "capi_pairs_scratch_count"}
     assert bound <= set(declared), sorted(bound - set(declared))
     assert L.capi_version() >= 100
 

@@ -198,6 +198,43 @@ def test_tall_skinny_gram_and_right_trmm(m, n, pad):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("m", [16384, 65536 + 32, 32 * 3001])
+def test_panel32_images_match_column_major(m):
+    """The "panel32" forms of the two tall-skinny kernels (include/capital_hip.h; qr::cacqr keeps CholeskyQR2's intermediate Q1 in this
+    layout, cacqr.hpp:174-193): the Gram matrix of an image and Q = B T with either side as an image must equal the column-major calls
+    BIT FOR BIT -- the layout changes addresses only, not the order of any sum -- and a plain fp64 torch product to 1e-13."""
+    import torch
+    from capital_amd import capi
+    h = capi.Handle(0)
+    n = 256
+    torch.manual_seed(m)
+    A = torch.rand((n, m), dtype=torch.float64, device="cuda") - 0.5            # column-major m x n
+    A32 = A.T.reshape(m // 32, 32, n).transpose(1, 2).contiguous()              # tile t: [column][32 rows]
+    T = torch.triu(torch.rand((n, n), dtype=torch.float64, device="cuda") - 0.5)
+    Tcm = T.T.contiguous()
+    G0, G1 = torch.zeros((n, n), dtype=torch.float64, device="cuda"), torch.zeros((n, n), dtype=torch.float64, device="cuda")
+    h.call("capi_dsyrk", 1, 1, n, m, 1.0, capi.ptr(A), m, 0.0, capi.ptr(G0), n)
+    h.call("capi_dsyrk_panel32", n, m, 1.0, capi.ptr(A32), 0.0, capi.ptr(G1), n)
+    Q0 = torch.zeros((n, m), dtype=torch.float64, device="cuda")
+    h.call("capi_dtrmm_oop", 1, 1, 0, 0, m, n, 0.75, capi.ptr(Tcm), n, capi.ptr(A), m, capi.ptr(Q0), m)
+    outs = {}
+    for src_t in (False, True):
+        for dst_t in (False, True):
+            if not (src_t or dst_t):
+                continue
+            Q = torch.zeros((m // 32, n, 32) if dst_t else (n, m), dtype=torch.float64, device="cuda")
+            h.call("capi_dtrmm_right_panel32", m, n, 0.75, capi.ptr(Tcm), n, capi.ptr(A32 if src_t else A), 0 if src_t else m, capi.ptr(Q), 0 if dst_t else m)
+            outs[(src_t, dst_t)] = Q.transpose(1, 2).reshape(m, n).T.contiguous() if dst_t else Q
+    h.sync()
+    assert torch.equal(G0, G1)
+    for k, Q in outs.items():
+        assert torch.equal(Q, Q0), k
+    Am = A.T
+    Qref = 0.75 * (Am @ T)
+    assert (Q0.T - Qref).abs().max().item() <= 1e-13 * Qref.abs().max().item()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,pad,uplo,trans,alpha,beta", [(512, 0, 1, 0, 1.0, 0.0), (768, 2, 1, 0, -0.5, 0.0), (1024, 0, 1, 0, 1.0, 0.0), (1024, 3, 0, 1, 2.0, 0.0),
                                                           (1000, 0, 1, 0, 1.0, 0.0), (1024, 0, 0, 0, 1.0, 0.0), (512, 2, 1, 1, 1.0, 0.0), (768, 0, 1, 0, 1.0, 0.75),
                                                           (2048, 0, 1, 0, 1.0, 0.0)])

@@ -1361,16 +1361,17 @@ __device__ __forceinline__ void trmm_ts_body(const GemmArgs& p, double* __restri
 template <int W>
 __device__ __forceinline__ void trmm_ts32_body(const GemmArgs& p, double* __restrict__ lds) {
   constexpr int SA = W, SB = 15 - W, NA = 4 * (SA + 1), NB = 4 * (SB + 1);   // strips and their k-step counts (NA <= NB)
-  constexpr int HALF = 256 * 16, TILE = 2 * HALF;          // LDS tile: [half][k][16 rows]
+  constexpr int HALF = 256 * 16, TILE = 2 * HALF;          // LDS tile: [half][k][16 rows]; half 0 = the tile's EVEN rows, half 1 = its odd rows
   const int tid = threadIdx.x, lane = tid & 63;
   const int r16 = lane & 15, g = lane >> 4;
   const int ntile = (p.M + 31) >> 5;
   double ta[NA], tb[NB];
+  // (alpha is folded into the stationary fragments: nothing is scaled on the way out; alpha == 1 -- CholeskyQR2 -- is exact either way)
   auto tget = [&](int k, int j) {
     double v = p.B[k + (int64_t)j * p.ldb];
     if (k > j) v = 0.0;
     if (p.tri_unit && k == j) v = 1.0;
-    return v;
+    return p.beta == 0.0 ? p.alpha * v : v;
   };
 #pragma unroll
   for (int s_ = 0; s_ < NA; ++s_) ta[s_] = tget(4 * s_ + g, 16 * SA + r16);
@@ -1382,7 +1383,11 @@ __device__ __forceinline__ void trmm_ts32_body(const GemmArgs& p, double* __rest
   // operand / output addressing: column-major (row + col ld) or panel32 (tile t at 32 * 256 * t, column stride 32)
   const int64_t acs = p.a_tiled ? 32 : p.lda, ats = p.a_tiled ? 32 * 256 : 32;     // A: column stride, tile stride
   const int64_t ccs = p.c_tiled ? 32 : p.ldc, cts = p.c_tiled ? 32 * 256 : 32;     // C likewise
-  const int lofs = (lr >> 4) * HALF + lc * 16 + (lr & 15);  // LDS offset of (rows lr, lr + 1; column lc)
+  // Rows 2i and 2i + 1 of a tile go to the two HALVES of its LDS image (index i in each): MFMA half h then computes rows 2 r16 + h, so a
+  // lane ends up with two CONSECUTIVE rows of every column it holds -- 16-byte stores, whole 256-byte column segments per store
+  // instruction, and no lane exchange on the way out (round 2 kept rows 0-15 / 16-31 in the halves and traded registers across lane
+  // pairs with DPP: 16 moves, 48 selects and 16 multiplies per tile and wave between two MFMA phases).
+  const int lofs = lc * 16 + (lr >> 1);                     // LDS offset (in either half) of row pair (lr, lr + 1) of column lc
   auto load = [&](int tile, d2_t (&st)[8]) {
     const bool in = 32 * tile + 32 <= p.M && p.a_vec;
     const double* src = in ? p.A + ats * tile + lr + (int64_t)lc * acs : p.A;
@@ -1393,7 +1398,7 @@ __device__ __forceinline__ void trmm_ts32_body(const GemmArgs& p, double* __rest
   auto stage = [&](double* L, int tile, const d2_t (&st)[8]) {
     if (p.a_vec && 32 * tile + 32 <= p.M) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) *(d2_t*)&L[lofs + 512 * q] = st[q];
+      for (int q = 0; q < 8; ++q) { L[lofs + 512 * q] = st[q].x; L[HALF + lofs + 512 * q] = st[q].y; }
       return;
     }
     const int r = 32 * tile + lr;
@@ -1403,7 +1408,7 @@ __device__ __forceinline__ void trmm_ts32_body(const GemmArgs& p, double* __rest
       d2_t v = {0.0, 0.0};
       if (r < p.M) v.x = p.A[ats * tile + lr + c * acs];
       if (r + 1 < p.M) v.y = p.A[ats * tile + lr + 1 + c * acs];
-      *(d2_t*)&L[lofs + 512 * q] = v;
+      L[lofs + 512 * q] = v.x; L[HALF + lofs + 512 * q] = v.y;
     }
   };
   const int t0 = blockIdx.x, dt = gridDim.x;
@@ -1421,7 +1426,7 @@ __device__ __forceinline__ void trmm_ts32_body(const GemmArgs& p, double* __rest
       for (int q = 0; q < 8; ++q) st[q] = TS_LOAD((const d2_t*)(src + q * 32 * acs));
     } else if (tile + dt < ntile) load(tile + dt, st);
     d4_t ca0 = {0.0, 0.0, 0.0, 0.0}, ca1 = ca0, cb0 = ca0, cb1 = ca0;
-    const double* la = L + g * 16 + r16;                    // A[row r16 (+16)][k = 4 s + g]
+    const double* la = L + g * 16 + r16;                    // A[row 2 r16 (+1)][k = 4 s + g]
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int s_ = 0; s_ < NB; ++s_) {
@@ -1437,57 +1442,37 @@ __device__ __forceinline__ void trmm_ts32_body(const GemmArgs& p, double* __rest
     if (STEADY) {
       double* Ln = lds + (par ^ 1) * TILE;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) *(d2_t*)&Ln[lofs + 512 * q] = st[q];
+      for (int q = 0; q < 8; ++q) { Ln[lofs + 512 * q] = st[q].x; Ln[HALF + lofs + 512 * q] = st[q].y; }
     } else if (tile + dt < ntile) stage(lds + (par ^ 1) * TILE, tile + dt, st);
     par ^= 1;
     __syncthreads();
-    // lane holds (i = row r16 (+16) of the tile, j = 16 strip + g + 4 reg): 16 lanes -> 128 contiguous bytes of one column
-    const int i = 32 * tile + r16;
-    double* c0_ = p.C + cts * tile + r16 + (int64_t)(16 * SA + g) * ccs;
-    double* c1_ = p.C + cts * tile + r16 + (int64_t)(16 * SB + g) * ccs;
+    // lane holds rows 2 r16, 2 r16 + 1 of columns j = 16 strip + g + 4 reg: one 16-byte store per column, 16 lanes -> the tile's whole
+    // 256-byte segment of that column
+    const int i = 32 * tile + 2 * r16;
+    double* c0_ = p.C + cts * tile + 2 * r16 + (int64_t)(16 * SA + g) * ccs;
+    double* c1_ = p.C + cts * tile + 2 * r16 + (int64_t)(16 * SB + g) * ccs;
     const int64_t s4 = 4 * ccs;
     if (STEADY) {
-      // 16-byte stores: lanes 2k and 2k+1 hold rows 2k, 2k+1 of the same columns, so a pair of registers (columns a, b) is
-      // traded across the lane pair -- the even lane ends with rows 2k, 2k+1 of column a, the odd lane with those of column b.
-      // (With 8-byte-per-lane stores WRITE_SIZE counted twice the bytes stored: the lines reached the fabric in halves.)
-      const bool odd = lane & 1;
-      auto swap1 = [](double v) {
-        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
-        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xF, 0xF, false);
-        return __hiloint2double(hi, lo);
-      };
-      auto put2 = [&](double* base, double va, double vb) {   // base: row 2k (this lane pair), column of register a; b = a + 4 columns
-        const double give = odd ? va : vb;
-        const double got = swap1(give);
-        d2_t out;
-        out.x = odd ? got : va;
-        out.y = odd ? vb : got;
-        TS_STORE((d2_t*)(base + (odd ? s4 : 0)), out);
-      };
-      double* e0 = c0_ - (lane & 1);                         // row 2k of this lane pair
-      double* e1 = c1_ - (lane & 1);
 #pragma unroll
-      for (int pr = 0; pr < 2; ++pr) {                       // register pairs (0,1) and (2,3): columns g + 8 pr and g + 8 pr + 4
-        put2(e0 + 2 * pr * s4, p.alpha * ca0[2 * pr], p.alpha * ca0[2 * pr + 1]);
-        put2(e0 + 2 * pr * s4 + 16, p.alpha * ca1[2 * pr], p.alpha * ca1[2 * pr + 1]);
-        put2(e1 + 2 * pr * s4, p.alpha * cb0[2 * pr], p.alpha * cb0[2 * pr + 1]);
-        put2(e1 + 2 * pr * s4 + 16, p.alpha * cb1[2 * pr], p.alpha * cb1[2 * pr + 1]);
+      for (int reg = 0; reg < 4; ++reg) {
+        TS_STORE((d2_t*)(c0_ + reg * s4), ((d2_t){ca0[reg], ca1[reg]}));
+        TS_STORE((d2_t*)(c1_ + reg * s4), ((d2_t){cb0[reg], cb1[reg]}));
       }
     } else {
-      const bool ok0 = i < p.M, ok1 = i + 16 < p.M;
-      if (p.beta == 0.0) {
+      const bool ok0 = i < p.M, ok1 = i + 1 < p.M;
+      if (p.beta == 0.0) {                                     // (alpha already sits in the fragments)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-          if (ok0) { c0_[reg * s4] = p.alpha * ca0[reg]; c1_[reg * s4] = p.alpha * cb0[reg]; }
-          if (ok1) { c0_[reg * s4 + 16] = p.alpha * ca1[reg]; c1_[reg * s4 + 16] = p.alpha * cb1[reg]; }
+          if (ok0) { c0_[reg * s4] = ca0[reg]; c1_[reg * s4] = cb0[reg]; }
+          if (ok1) { c0_[reg * s4 + 1] = ca1[reg]; c1_[reg * s4 + 1] = cb1[reg]; }
         }
       } else {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
           if (ok0) { c0_[reg * s4] = p.alpha * ca0[reg] + p.beta * c0_[reg * s4]; c1_[reg * s4] = p.alpha * cb0[reg] + p.beta * c1_[reg * s4]; }
           if (ok1) {
-            c0_[reg * s4 + 16] = p.alpha * ca1[reg] + p.beta * c0_[reg * s4 + 16];
-            c1_[reg * s4 + 16] = p.alpha * cb1[reg] + p.beta * c1_[reg * s4 + 16];
+            c0_[reg * s4 + 1] = p.alpha * ca1[reg] + p.beta * c0_[reg * s4 + 1];
+            c1_[reg * s4 + 1] = p.alpha * cb1[reg] + p.beta * c1_[reg * s4 + 1];
           }
         }
       }

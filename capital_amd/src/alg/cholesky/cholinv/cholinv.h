@@ -151,7 +151,9 @@ public:
     const U h = localDimension - (localDimension >> args.split);
     const U agg = args.bcDimension;
     // (single GPU: the R12 copies of nested levels stay live while their trailing updates run beside the recursion: h^2 (1 + 1/4 + ...))
-    int64_t need = single ? (int64_t)h * h + (int64_t)h * h / 3 + 1024 : (int64_t)8 * h * h + 4 * (int64_t)agg * agg + 1024;
+    // (grids: the update's W, its exchanged copy + staging, two panels, the partial sums + their packed image, relay space and the landing
+    //  half of the multi-path pair transfers, per-chunk copies of a pipelined multiply)
+    int64_t need = single ? (int64_t)h * h + (int64_t)h * h / 3 + 1024 : (int64_t)12 * h * h + 4 * (int64_t)agg * agg + 4096;
     args.work.reserve(need);
 
     args.la_depth = 0;
@@ -332,9 +334,14 @@ private:
       } else {
         // partner-exchanged copy of R11^-1 (cholinv.hpp:116-117)
         view Tx{ws.take((int64_t)split1 * split1), split1, split1, split1};
-        if (t.x == t.y || getenv("CAPITAL_NO_PACKED_COMM")) {
+        // (on a grid that relays every rank joins the exchange with the same, packed, count: the diagonal ranks carry other pairs' units)
+        if ((t.x == t.y && !t.multipath) || getenv("CAPITAL_NO_PACKED_COMM")) {
           CAPITAL_CHECK(capi_dlacpy(h, 0, split1, split1, R11i.p, ld, Tx.p, Tx.ld));
-          util::transpose_raw(Tx.p, Tx.count(), ws.take(Tx.count()), t);
+          util::transpose_raw(Tx.p, Tx.count(), ws.take(Tx.count()), t, matmult::summa::relay_space(t, Tx.count(), ws));
+        } else if (t.x == t.y) {
+          const int64_t np = (int64_t)split1 * (split1 + 1) / 2;
+          CAPITAL_CHECK(capi_dlacpy(h, 0, split1, split1, R11i.p, ld, Tx.p, Tx.ld));
+          util::transpose_raw(nullptr, np, nullptr, t, matmult::summa::relay_space(t, np, ws));
         } else {
           // the exchanged block is upper triangular: it crosses the link packed (n(n+1)/2) and is unpacked on arrival;
           // the strictly-lower half of Tx is never read (TRMM masks by selection)
@@ -342,7 +349,7 @@ private:
           double* pk = ws.take(np);
           CAPITAL_CHECK(capi_serialize_shape(h, CAPI_UPPERTRI, CAPI_RECT, CAPI_UPPERTRI, R11i.p, split1, ld, pk, split1, split1,
                                              0, split1, 0, split1, 0, split1, 0, split1));
-          util::transpose_raw(pk, np, ws.take(np), t);
+          util::transpose_raw(pk, np, ws.take(np), t, matmult::summa::relay_space(t, np, ws));
           CAPITAL_CHECK(capi_serialize_shape(h, CAPI_UPPERTRI, CAPI_UPPERTRI, CAPI_RECT, pk, split1, split1, Tx.p, split1, split1,
                                              0, split1, 0, split1, 0, split1, 0, split1));
         }
@@ -399,7 +406,7 @@ private:
       } else {
         view Wx{ws.take(W.count()), split1, split1, split2};
         capital::dev_copy(Wx.p, W.p, W.count());
-        util::transpose_raw(Wx.p, Wx.count(), ws.take(Wx.count()), t);
+        util::transpose_raw(Wx.p, Wx.count(), ws.take(Wx.count()), t, matmult::summa::relay_space(t, Wx.count(), ws));
         matmult::summa::syrk(t, CAPI_UPPER, CAPI_TRANS, -1.0, W, Wx, 1.0, A22, ws);
       }
       if (pack_now && !packed_early) {

@@ -102,6 +102,8 @@ public:
 
   // ---- view-level engine (used directly by cholinv / cacqr) ---------------------------------------------------------
   // C <- alpha*op(A)*op(B) + beta*C.  Operand blocks are the LOCAL blocks of this rank; roots are chosen per K-class.
+  // With num_chunks > 0 (one K-class per layer, op(B) = B): A first, then B and the product column chunk by column chunk --
+  // bcast of chunk j+1 || MFMA on chunk j || depth all-reduce of chunk j-1 (summa.hpp:195-215,238-249).
   template <typename CommType>
   static void gemm(CommType&& t, int transA, int transB, double alpha, view A, view B, double beta, view C, arena& ws) {
     capi_handle_t h = capital::handle();
@@ -112,25 +114,85 @@ public:
     }
     const int64_t mark = ws.top;
     view acc = t.c > 1 ? view{ws.take(M * N), M, M, N} : C;
-    if (t.d == 1) {
-      // pure replication: layer z multiplies its slice of the local K range
-      int64_t k0, k1;
-      kslice(K, t.c, t.z, k0, k1);
-      const double* a = transA ? A.p + k0 : A.p + k0 * A.ld;
-      const double* b = transB ? B.p + k0 * B.ld : B.p + k0;
-      CAPITAL_CHECK(capi_dgemm(h, transA, transB, M, N, k1 - k0, alpha, a, A.ld, b, B.ld, 0.0, acc.p, acc.ld));
-    } else {
-      const size_t steps = t.d / t.c;
-      for (size_t s = 0; s < steps; ++s) {
-        const size_t q = t.z + s * t.c;
-        view a = panel(t.row, t.x == q, (int)q, A, ws), b = panel(t.column, t.y == q, (int)q, B, ws);
-        const double bt = (t.c > 1) ? (s ? 1.0 : 0.0) : (s ? 1.0 : beta);
-        CAPITAL_CHECK(capi_dgemm(h, transA, transB, M, N, K, alpha, a.p, a.ld, b.p, b.ld, bt, acc.p, acc.ld));
+    const size_t steps = t.d > 1 ? t.d / t.c : 1;
+    const bool piped = t.num_chunks > 0 && steps == 1 && transB == CAPI_NOTRANS && (t.d > 1 || t.c > 1);
+    const int nch = piped ? chunk_count(t.num_chunks, N) : 1;
+    pipe P(piped && nch > 1);
+    enum { E0 = 0, EA = 1, EB = 2, EC = 70, ER = 140 };
+    if (!P.on) {
+      if (t.d == 1) {
+        // pure replication: layer z multiplies its slice of the local K range
+        int64_t k0, k1;
+        kslice(K, t.c, t.z, k0, k1);
+        const double* a = transA ? A.p + k0 : A.p + k0 * A.ld;
+        const double* b = transB ? B.p + k0 * B.ld : B.p + k0;
+        CAPITAL_CHECK(capi_dgemm(h, transA, transB, M, N, k1 - k0, alpha, a, A.ld, b, B.ld, 0.0, acc.p, acc.ld));
+      } else {
+        for (size_t s = 0; s < steps; ++s) {
+          view a = panel(t, AX_ROW, s, A, ws), b = panel(t, AX_COLUMN, s, B, ws);
+          const double bt = (t.c > 1) ? (s ? 1.0 : 0.0) : (s ? 1.0 : beta);
+          CAPITAL_CHECK(capi_dgemm(h, transA, transB, M, N, K, alpha, a.p, a.ld, b.p, b.ld, bt, acc.p, acc.ld));
+        }
       }
+      if (t.c > 1) {
+        allreduce_depth(t, acc.p, acc.count(), ws);
+        CAPITAL_CHECK(capi_dgeadd(h, 0, M, N, 1.0, acc.p, acc.ld, beta, C.p, C.ld));
+      }
+      ws.top = mark;
+      return;
+    }
+    // ---- pipelined over the output's column chunks
+    const bool sliced = (t.d == 1);
+    int64_t k0 = 0, k1 = K;
+    view a = A, b = B;
+    const size_t q = t.z;
+    const bool rootB = sliced || (t.y == q);
+    P.main(); P.rec(E0);
+    P.comm(); P.wait(E0);
+    if (sliced) {
+      kslice(K, t.c, t.z, k0, k1);
+    } else {
+      a = panel(t, AX_ROW, 0, A, ws);
+      b = view{(rootB && B.contiguous()) ? B.p : ws.take(B.count()), B.rows, B.rows, B.cols};
+    }
+    P.rec(EA);
+    int64_t cmax = 0;
+    for (int j = 0; j < nch; ++j) { int64_t c0, c1; chunk_range(N, nch, j, c0, c1); cmax = std::max(cmax, c1 - c0); }
+    double* relay = relay_space(t, std::max(b.rows, acc.rows) * cmax, ws);
+    for (int j = 0; j < nch; ++j) {
+      int64_t c0, c1;
+      chunk_range(N, nch, j, c0, c1);
+      if (!sliced && c1 > c0) {
+        if (rootB && !B.contiguous()) CAPITAL_CHECK(capi_dlacpy(h, 0, B.rows, c1 - c0, B.p + c0 * B.ld, B.ld, b.p + c0 * b.ld, b.ld));
+        bcast_axis(t, AX_COLUMN, 0, b.p + c0 * b.ld, b.rows * (c1 - c0), relay);
+      }
+      P.rec(EB + j);
+    }
+    P.main(); P.wait(EA);
+    const double bt = t.c > 1 ? 0.0 : beta;
+    const double* ap = sliced ? (transA ? a.p + k0 : a.p + k0 * a.ld) : a.p;
+    for (int j = 0; j < nch; ++j) {
+      int64_t c0, c1;
+      chunk_range(N, nch, j, c0, c1);
+      P.wait(EB + j);
+      if (c1 > c0)
+        CAPITAL_CHECK(capi_dgemm(h, transA, CAPI_NOTRANS, M, c1 - c0, k1 - k0, alpha, ap, a.ld, b.p + k0 + c0 * b.ld, b.ld, bt, acc.p + c0 * acc.ld, acc.ld));
+      P.rec(EC + j);
     }
     if (t.c > 1) {
-      CAPITAL_CHECK(capi_allreduce_sum(t.depth, acc.p, acc.count()));
+      P.comm();
+      double* half = depth_space(t, acc.rows * cmax, ws);
+      for (int j = 0; j < nch; ++j) {
+        int64_t c0, c1;
+        chunk_range(N, nch, j, c0, c1);
+        P.wait(EC + j);
+        if (c1 > c0) allreduce_depth(t, acc.p + c0 * acc.ld, acc.rows * (c1 - c0), half, relay);
+      }
+      P.rec(ER);
+      P.main(); P.wait(ER);
       CAPITAL_CHECK(capi_dgeadd(h, 0, M, N, 1.0, acc.p, acc.ld, beta, C.p, C.ld));
+    } else {
+      P.main();
     }
     ws.top = mark;
   }
@@ -177,17 +239,23 @@ public:
     }
     const int64_t mark = ws.top;
     const size_t steps = t.d > 1 ? t.d / t.c : 1;
-    // the output-column pipeline is built for the one-step cases (c == d as in the reference, or d == 1) of a left multiply
-    const bool piped = t.num_chunks > 0 && side == CAPI_LEFT && steps == 1 && Cout.contiguous();
+    const bool eff_upper = (uplo == CAPI_UPPER) != (trans == CAPI_TRANS);
+    // The output-column pipeline serves the one-step cases (c == d as in the reference, or d == 1): every left multiply, and the
+    // right multiply with an upper, untransposed T (the inverse completion, cholinv.hpp:150-154; cacqr.hpp:108-112) -- there column
+    // chunk j of the output needs B's column chunks 0..j, which arrive in that order.
+    const bool piped_left = side == CAPI_LEFT;
+    const bool piped_right = side == CAPI_RIGHT && eff_upper && trans == CAPI_NOTRANS && t.d > 1;
+    const bool piped = t.num_chunks > 0 && (piped_left || piped_right) && steps == 1 && Cout.contiguous();
     const int nch = piped ? chunk_count(t.num_chunks, N) : 1;
     pipe P(piped && nch > 1);
     enum { E0 = 0, ET = 1, EB = 2, EC = 70, ER = 140 };
+    int64_t cmax = N;
+    if (P.on) { cmax = 0; for (int j = 0; j < nch; ++j) { int64_t c0, c1; chunk_range(N, nch, j, c0, c1); cmax = std::max(cmax, c1 - c0); } }
     if (t.d == 1) {
       // K-slice [k0,k1) of a triangular operand: a triangle on the diagonal plus a rectangle beside it
       const int64_t K = T.rows;
       int64_t k0, k1;
       kslice(K, t.c, t.z, k0, k1);
-      const bool eff_upper = (uplo == CAPI_UPPER) != (trans == CAPI_TRANS);
       for (int j = 0; j < nch; ++j) {
         int64_t c0 = 0, c1 = N;
         if (nch > 1) chunk_range(N, nch, j, c0, c1);
@@ -225,28 +293,29 @@ public:
       }
     } else if (!P.on) {
       for (size_t s = 0; s < steps; ++s) {
-        const size_t q = t.z + s * t.c;
         view tt, bb;
-        if (side == CAPI_LEFT) { tt = panel_tri(t.row, t.x == q, (int)q, T, uplo, ws); bb = panel(t.column, t.y == q, (int)q, B, ws); }
-        else { bb = panel(t.row, t.x == q, (int)q, B, ws); tt = panel_tri(t.column, t.y == q, (int)q, T, uplo, ws); }
+        if (side == CAPI_LEFT) { tt = panel_tri(t, AX_ROW, s, T, uplo, ws); bb = panel(t, AX_COLUMN, s, B, ws); }
+        else { bb = panel(t, AX_ROW, s, B, ws); tt = panel_tri(t, AX_COLUMN, s, T, uplo, ws); }
         CAPITAL_CHECK(capi_dtrmm_acc(h, side, uplo, trans, diag, M, N, alpha, tt.p, tt.ld, bb.p, bb.ld, s ? 1.0 : 0.0, Cout.p, Cout.ld));
       }
     } else {
-      // one K-class (q = z), left multiply: T first, then B column chunk by column chunk on the communication stream
+      // one K-class (q = z): T first (whole, packed), then B column chunk by column chunk on the communication stream
       const size_t q = t.z;
-      const bool rootB = (t.y == q);
+      const int axB = side == CAPI_LEFT ? AX_COLUMN : AX_ROW;
+      const bool rootB = (side == CAPI_LEFT ? t.y : t.x) == q;
       P.main(); P.rec(E0);
       P.comm(); P.wait(E0);
-      view tt = panel(t.row, t.x == q, (int)q, T, ws);
+      view tt = panel_tri(t, side == CAPI_LEFT ? AX_ROW : AX_COLUMN, 0, T, uplo, ws);
       P.rec(ET);
       view bb{nullptr, B.rows, B.rows, B.cols};
       bb.p = (rootB && B.contiguous()) ? B.p : ws.take(B.count());
+      double* relay = relay_space(t, B.rows * cmax, ws);
       for (int j = 0; j < nch; ++j) {
         int64_t c0, c1;
         chunk_range(N, nch, j, c0, c1);
         if (c1 > c0) {
           if (rootB && !B.contiguous()) CAPITAL_CHECK(capi_dlacpy(h, 0, B.rows, c1 - c0, B.p + c0 * B.ld, B.ld, bb.p + c0 * bb.ld, bb.ld));
-          CAPITAL_CHECK(capi_bcast(t.column, bb.p + c0 * bb.ld, bb.rows * (c1 - c0), (int)q));
+          bcast_axis(t, axB, 0, bb.p + c0 * bb.ld, bb.rows * (c1 - c0), relay);
         }
         P.rec(EB + j);
       }
@@ -255,24 +324,36 @@ public:
         int64_t c0, c1;
         chunk_range(N, nch, j, c0, c1);
         P.wait(EB + j);
-        if (c1 > c0)
-          CAPITAL_CHECK(capi_dtrmm_oop(h, side, uplo, trans, diag, M, c1 - c0, alpha, tt.p, tt.ld, bb.p + c0 * bb.ld, bb.ld, Cout.p + c0 * Cout.ld, Cout.ld));
+        if (c1 > c0) {
+          double* Cj = Cout.p + c0 * Cout.ld;
+          if (side == CAPI_LEFT) {
+            CAPITAL_CHECK(capi_dtrmm_oop(h, side, uplo, trans, diag, M, c1 - c0, alpha, tt.p, tt.ld, bb.p + c0 * bb.ld, bb.ld, Cj, Cout.ld));
+          } else {
+            // Cout[:, chunk] = alpha ( B[:, 0:c0] T[0:c0, chunk] + B[:, chunk] T[chunk, chunk] ): a rectangle above the chunk's triangle
+            if (c0 > 0)
+              CAPITAL_CHECK(capi_dgemm(h, CAPI_NOTRANS, CAPI_NOTRANS, M, c1 - c0, c0, alpha, bb.p, bb.ld, tt.p + c0 * tt.ld, tt.ld, 0.0, Cj, Cout.ld));
+            CAPITAL_CHECK(capi_dtrmm_acc(h, side, uplo, trans, diag, M, c1 - c0, alpha, tt.p + c0 + c0 * tt.ld, tt.ld, bb.p + c0 * bb.ld, bb.ld,
+                                         c0 > 0 ? 1.0 : 0.0, Cj, Cout.ld));
+          }
+        }
         P.rec(EC + j);
       }
     }
     if (t.c > 1) {
       if (P.on) {
         P.comm();
+        double* relay = relay_space(t, Cout.rows * cmax, ws);
+        double* half = depth_space(t, Cout.rows * cmax, ws);
         for (int j = 0; j < nch; ++j) {
           int64_t c0, c1;
           chunk_range(N, nch, j, c0, c1);
           P.wait(EC + j);
-          if (c1 > c0) CAPITAL_CHECK(capi_allreduce_sum(t.depth, Cout.p + c0 * Cout.ld, Cout.rows * (c1 - c0)));
+          if (c1 > c0) allreduce_depth(t, Cout.p + c0 * Cout.ld, Cout.rows * (c1 - c0), half, relay);
         }
         P.rec(ER);
         P.main(); P.wait(ER);
       } else {
-        allreduce_view(t.depth, Cout, ws);
+        allreduce_view(t, Cout, ws);
       }
     } else if (P.on) {
       P.main();
@@ -312,17 +393,16 @@ public:
         CAPITAL_CHECK(capi_dgemmt(h, uplo, tA, tB, N, k1 - k0, alpha, l, L.ld, r, Rr.ld, 0.0, acc.p, acc.ld));
       } else {
         for (size_t s = 0; s < steps; ++s) {
-          const size_t q = t.z + s * t.c;
           view l, r;
-          if (trans) { l = panel(t.row, t.x == q, (int)q, Bx, ws); r = panel(t.column, t.y == q, (int)q, A, ws); }   // distribute(B,A)
-          else { l = panel(t.row, t.x == q, (int)q, A, ws); r = panel(t.column, t.y == q, (int)q, Bx, ws); }        // distribute(A,B)
+          if (trans) { l = panel(t, AX_ROW, s, Bx, ws); r = panel(t, AX_COLUMN, s, A, ws); }   // distribute(B,A)
+          else { l = panel(t, AX_ROW, s, A, ws); r = panel(t, AX_COLUMN, s, Bx, ws); }        // distribute(A,B)
           const double bt = (t.c > 1) ? (s ? 1.0 : 0.0) : (s ? 1.0 : beta);
           CAPITAL_CHECK(capi_dgemmt(h, uplo, tA, tB, N, K, alpha, l.p, l.ld, r.p, r.ld, bt, acc.p, acc.ld));
         }
       }
       if (t.c > 1) {
         // only the computed triangle is folded into C (and only it travels)
-        allreduce_tri(t.depth, acc, uplo, ws);
+        allreduce_tri(t, acc, uplo, ws);
         CAPITAL_CHECK(capi_dgeadd(h, uplo == CAPI_UPPER ? 1 : 2, N, N, 1.0, acc.p, acc.ld, beta, C.p, C.ld));
       }
       ws.top = mark;
@@ -334,21 +414,24 @@ public:
     const bool sliced = (t.d == 1);
     const size_t q = t.z;
     const bool rootR = sliced || (t.y == q);
+    int64_t cmax = 0;
+    for (int j = 0; j < nch; ++j) { int64_t c0, c1; chunk_range(N, nch, j, c0, c1); cmax = std::max(cmax, c1 - c0); }
     P.main(); P.rec(E0);
     P.comm(); P.wait(E0);
     if (sliced) {
       kslice(K, t.c, t.z, k0, k1);
     } else {
-      l = panel(t.row, t.x == q, (int)q, Bx, ws);
+      l = panel(t, AX_ROW, 0, Bx, ws);
       r = view{(rootR && A.contiguous()) ? A.p : ws.take(A.count()), A.rows, A.rows, A.cols};
     }
     P.rec(EL);
+    double* relay = relay_space(t, std::max(A.rows, N) * cmax, ws);
     for (int j = 0; j < nch; ++j) {
       int64_t c0, c1;
       chunk_range(N, nch, j, c0, c1);
       if (!sliced && c1 > c0) {
         if (rootR && !A.contiguous()) CAPITAL_CHECK(capi_dlacpy(h, 0, A.rows, c1 - c0, A.p + c0 * A.ld, A.ld, r.p + c0 * r.ld, r.ld));
-        CAPITAL_CHECK(capi_bcast(t.column, r.p + c0 * r.ld, r.rows * (c1 - c0), (int)q));
+        bcast_axis(t, AX_COLUMN, 0, r.p + c0 * r.ld, r.rows * (c1 - c0), relay);
       }
       P.rec(EB + j);
     }
@@ -370,11 +453,13 @@ public:
     }
     if (t.c > 1) {
       P.comm();
+      double* half = depth_space(t, acc.rows * cmax, ws);
       for (int j = 0; j < nch; ++j) {
         int64_t c0, c1;
         chunk_range(N, nch, j, c0, c1);
         P.wait(EC + j);
-        if (c1 > c0) CAPITAL_CHECK(capi_allreduce_sum(t.depth, acc.p + c0 * acc.ld, acc.rows * (c1 - c0)));
+        // (rows 0 .. c1 of the chunk's columns hold the computed part; the zeros below it are not sent)
+        if (c1 > c0) allreduce_cols(t, acc.p + c0 * acc.ld, acc.ld, c1, c1 - c0, half, relay, ws);
       }
       P.rec(ER);
       P.main(); P.wait(ER);
@@ -399,6 +484,69 @@ public:
     k1 = std::min<int64_t>(K, k0 + per);
   }
 
+  enum { AX_ROW = 0, AX_COLUMN = 1 };
+
+  // ---- pair collectives: over every link of the node (capi_pairs_transfer, csrc/pair_paths.h) when the grid's rows / columns /
+  //      depth fibres are pairs, else as RCCL calls on the sub-communicators ---------------------------------------------------------
+  // relay space for transfers of up to `count` doubles (nullptr when this grid does not relay)
+  template <typename CommType>
+  static double* relay_space(CommType&& t, int64_t count, arena& ws) {
+    if (!t.multipath) return nullptr;
+    const int64_t n = capi_pairs_scratch_count(t.size, count);
+    return n > 0 ? ws.take(n) : nullptr;
+  }
+  // landing space for the partner's half in a pair all-reduce of up to `count` doubles
+  template <typename CommType>
+  static double* depth_space(CommType&& t, int64_t count, arena& ws) { return t.pairs_in_depth() ? ws.take(count / 2 + 2) : nullptr; }
+
+  // MPI_Bcast(row | column) of `count` doubles at `buf`, root = the member whose x (y) is this layer's K-class at step s (summa.hpp:185,193)
+  template <typename CommType>
+  static void bcast_axis(CommType&& t, int axis, size_t s, double* buf, int64_t count, double* relay) {
+    const size_t q = t.z + s * t.c;
+    if (t.pairs_along(axis)) {
+      const bool root = (axis == AX_ROW ? t.x : t.y) == q;
+      const std::vector<int> dst = t.bcast_dst(axis, s);
+      CAPITAL_CHECK(capi_pairs_transfer(t.world, dst.data(), root ? buf : nullptr, root ? nullptr : buf, count, relay));
+    } else {
+      CAPITAL_CHECK(capi_bcast(axis == AX_ROW ? t.row : t.column, buf, count, (int)q));
+    }
+  }
+  // MPI_Allreduce(depth, SUM) in place (summa.hpp:236).  On a depth PAIR: each member keeps one half, the halves that are not kept
+  // cross over (all links), are added, and the sums cross back -- the bytes of a two-rank ring, at the multi-path rate.  a + b is
+  // commutative in IEEE arithmetic, so both members end with bit-identical sums.
+  template <typename CommType>
+  static void allreduce_depth(CommType&& t, double* buf, int64_t count, double* half_space, double* relay) {
+    const int64_t c4 = count & ~(int64_t)3, half = c4 / 2;
+    if (!t.pairs_in_depth() || half == 0) { CAPITAL_CHECK(capi_allreduce_sum(t.depth, buf, count)); return; }
+    const std::vector<int> dst = t.depth_dst();
+    double* keep = buf + (t.z == 0 ? 0 : half);
+    double* give = buf + (t.z == 0 ? half : 0);
+    CAPITAL_CHECK(capi_pairs_transfer(t.world, dst.data(), give, half_space, half, relay));
+    CAPITAL_CHECK(capi_daxpby(capital::handle(), half, 1.0, half_space, keep));
+    CAPITAL_CHECK(capi_pairs_transfer(t.world, dst.data(), keep, give, half, relay));
+    if (count > c4) CAPITAL_CHECK(capi_allreduce_sum(t.depth, buf + c4, count - c4));     // (at most three trailing values)
+  }
+  template <typename CommType>
+  static void allreduce_depth(CommType&& t, double* buf, int64_t count, arena& ws) {
+    const int64_t mark = ws.top;
+    double* half = depth_space(t, count, ws);
+    double* relay = t.pairs_in_depth() ? relay_space(t, count / 2 + 2, ws) : nullptr;
+    allreduce_depth(t, buf, count, half, relay);
+    ws.top = mark;
+  }
+  // sum over depth of `rows` x `cols` values at p (leading dimension ld); a strided block travels as a contiguous copy
+  // (half_space / relay sized for rows * cols; arena space taken here stays taken until the caller resets its mark: the copies
+  //  live on the communication stream of a pipelined multiply)
+  template <typename CommType>
+  static void allreduce_cols(CommType&& t, double* p, int64_t ld, int64_t rows, int64_t cols, double* half_space, double* relay, arena& ws) {
+    if (rows == ld) { allreduce_depth(t, p, rows * cols, half_space, relay); return; }
+    capi_handle_t h = capital::handle();
+    double* tmp = ws.take(rows * cols);
+    CAPITAL_CHECK(capi_dlacpy(h, 0, rows, cols, p, ld, tmp, rows));
+    allreduce_depth(t, tmp, rows * cols, half_space, relay);
+    CAPITAL_CHECK(capi_dlacpy(h, 0, rows, cols, tmp, rows, p, ld));
+  }
+
   // The panel a rank multiplies with: the root's own block (packed to contiguous if it is a strided view) broadcast
   // over `comm`.  Non-roots receive into arena memory.  Blocks have equal shapes on all ranks of a communicator.
   static view panel(capi_comm_t comm, bool is_root, int root, const view& mine, arena& ws) {
@@ -415,43 +563,71 @@ public:
     CAPITAL_CHECK(capi_bcast(comm, out.p, out.count(), root));
     return out;
   }
+  // the same along an axis of the grid at K-class step s (multi-path on grids of pairs)
+  template <typename CommType>
+  static view panel(CommType&& t, int axis, size_t s, const view& mine, arena& ws) {
+    const size_t q = t.z + s * t.c;
+    const bool is_root = (axis == AX_ROW ? t.x : t.y) == q;
+    if (!t.pairs_along(axis)) return panel(axis == AX_ROW ? t.row : t.column, is_root, (int)q, mine, ws);
+    view out{nullptr, mine.rows, mine.rows, mine.cols};
+    if (is_root && mine.contiguous()) {
+      out.p = mine.p;
+    } else {
+      out.p = ws.take(mine.count());
+      if (is_root) CAPITAL_CHECK(capi_dlacpy(capital::handle(), 0, mine.rows, mine.cols, mine.p, mine.ld, out.p, out.ld));
+    }
+    const int64_t mark = ws.top;
+    bcast_axis(t, axis, s, out.p, out.count(), relay_space(t, out.count(), ws));
+    ws.top = mark;                                              // (relay space is reused in stream order)
+    return out;
+  }
   // A TRIANGULAR operand travels packed (n(n+1)/2 doubles instead of n^2, the reference's Serialize policy on the wire,
   // summa.hpp:147-148,216-217): the root packs, everyone unpacks the triangle into a full-stride buffer whose other half is
   // never read (the kernels truncate each tile's k-range at the diagonal and mask the diagonal panels by selection).
-  static view panel_tri(capi_comm_t comm, bool is_root, int root, const view& mine, int uplo, arena& ws) {
+  template <typename CommType>
+  static view panel_tri(CommType&& t, int axis, size_t s, const view& mine, int uplo, arena& ws) {
+    capi_comm_t comm = axis == AX_ROW ? t.row : t.column;
     int size = 1;
     CAPITAL_CHECK(capi_comm_size(comm, &size));
     if (size == 1) return mine;
     static const bool off = getenv("CAPITAL_NO_PACKED_COMM") != nullptr;
-    if (off || mine.rows != mine.cols) return panel(comm, is_root, root, mine, ws);
+    if (off || mine.rows != mine.cols) return panel(t, axis, s, mine, ws);
     capi_handle_t h = capital::handle();
+    const size_t q = t.z + s * t.c;
+    const bool is_root = (axis == AX_ROW ? t.x : t.y) == q;
     const int64_t n = mine.rows, np = n * (n + 1) / 2;
     const int st = uplo == CAPI_UPPER ? CAPI_UPPERTRI : CAPI_LOWERTRI;
     double* packed = ws.take(np);
     if (is_root) CAPITAL_CHECK(capi_serialize_shape(h, st, CAPI_RECT, st, mine.p, n, mine.ld, packed, n, n, 0, n, 0, n, 0, n, 0, n));
-    CAPITAL_CHECK(capi_bcast(comm, packed, np, root));
+    {
+      const int64_t mark = ws.top;
+      bcast_axis(t, axis, s, packed, np, relay_space(t, np, ws));
+      ws.top = mark;
+    }
     if (is_root) return mine;                                   // the root multiplies with its own block
     view out{ws.take(n * n), n, n, n};
     CAPITAL_CHECK(capi_serialize_shape(h, st, st, CAPI_RECT, packed, n, n, out.p, n, n, 0, n, 0, n, 0, n, 0, n));
     return out;
   }
-  // sum over `comm` of the `uplo` triangle of a contiguous n x n accumulator, packed on the wire
-  static void allreduce_tri(capi_comm_t comm, view acc, int uplo, arena& ws) {
+  // sum over depth of the `uplo` triangle of a contiguous n x n accumulator, packed on the wire
+  template <typename CommType>
+  static void allreduce_tri(CommType&& t, view acc, int uplo, arena& ws) {
     static const bool off = getenv("CAPITAL_NO_PACKED_COMM") != nullptr;
-    if (off || acc.rows != acc.cols || !acc.contiguous()) { CAPITAL_CHECK(capi_allreduce_sum(comm, acc.p, acc.count())); return; }
+    if (off || acc.rows != acc.cols || !acc.contiguous()) { allreduce_depth(t, acc.p, acc.count(), ws); return; }
     capi_handle_t h = capital::handle();
     const int64_t n = acc.rows, np = n * (n + 1) / 2;
     const int st = uplo == CAPI_UPPER ? CAPI_UPPERTRI : CAPI_LOWERTRI;
     double* packed = ws.take(np);
     CAPITAL_CHECK(capi_serialize_shape(h, st, CAPI_RECT, st, acc.p, n, n, packed, n, n, 0, n, 0, n, 0, n, 0, n));
-    CAPITAL_CHECK(capi_allreduce_sum(comm, packed, np));
+    allreduce_depth(t, packed, np, ws);
     CAPITAL_CHECK(capi_serialize_shape(h, st, st, CAPI_RECT, packed, n, n, acc.p, n, n, 0, n, 0, n, 0, n, 0, n));
   }
-  static void allreduce_view(capi_comm_t comm, view v, arena& ws) {
-    if (v.contiguous()) { CAPITAL_CHECK(capi_allreduce_sum(comm, v.p, v.count())); return; }
+  template <typename CommType>
+  static void allreduce_view(CommType&& t, view v, arena& ws) {
+    if (v.contiguous()) { allreduce_depth(t, v.p, v.count(), ws); return; }
     double* tmp = ws.take(v.count());
     CAPITAL_CHECK(capi_dlacpy(capital::handle(), 0, v.rows, v.cols, v.p, v.ld, tmp, v.rows));
-    CAPITAL_CHECK(capi_allreduce_sum(comm, tmp, v.count()));
+    allreduce_depth(t, tmp, v.count(), ws);
     CAPITAL_CHECK(capi_dlacpy(capital::handle(), 0, v.rows, v.cols, tmp, v.rows, v.p, v.ld));
   }
 };

@@ -11,12 +11,25 @@ class util {
 public:
   // util.hpp:232-247: swap the local block with the (y,x) partner; elements are NOT transposed locally -- consumers
   // pass a Trans flag instead.  One xGMI link, both directions.  `staging` must hold mat.num_elems() doubles.
+  // On a grid that relays (topo::square::multipath) the exchange is a grid-wide set of pair transfers over all links of the node
+  // (capi_pairs_transfer): EVERY rank calls, with the same count -- the diagonal ranks (x == y) exchange nothing themselves but carry
+  // other pairs' units; `relay` = capi_pairs_scratch_count(size, count) doubles.
   template <typename MatrixType, typename CommType>
   static void transpose(MatrixType& mat, CommType&& CommInfo) {
-    transpose_raw(mat.data(), mat.num_elems(), mat.scratch(), CommInfo);
+    double* relay = nullptr;
+    if (CommInfo.multipath) relay = capital::dev_alloc(capi_pairs_scratch_count(CommInfo.size, mat.num_elems()));
+    transpose_raw(mat.data(), mat.num_elems(), mat.scratch(), CommInfo, relay);
+    if (relay) { capital::sync(); capital::dev_free(relay); }
   }
   template <typename CommType>
-  static void transpose_raw(double* buf, int64_t count, double* staging, CommType&& CommInfo) {
+  static void transpose_raw(double* buf, int64_t count, double* staging, CommType&& CommInfo, double* relay = nullptr) {
+    if (CommInfo.multipath) {
+      const std::vector<int> dst = CommInfo.transpose_dst();
+      const bool moves = CommInfo.x != CommInfo.y;
+      CAPITAL_CHECK(capi_pairs_transfer(CommInfo.world, dst.data(), moves ? buf : nullptr, moves ? staging : nullptr, count, relay));
+      if (moves) capital::dev_copy(buf, staging, count);
+      return;
+    }
     if (CommInfo.x == CommInfo.y) return;
     const int partner = CommInfo.rank_of(CommInfo.y, CommInfo.x, CommInfo.z);
     CAPITAL_CHECK(capi_sendrecv_replace(CommInfo.world, buf, count, partner, staging));

@@ -153,7 +153,7 @@ def main():
         p.close()
     else:
         q = driver.Cacqr(cfg["m"], cfg["n"], c=cfg.get("c", 1), variant=cfg["variant"], complete_inv=cfg.get("ci", 0), bc_mult=cfg.get("bc", 0),
-                         serialize=cfg["serialize"])
+                         num_chunks=cfg.get("chunks", 0), serialize=cfg["serialize"])
         q.generate()
         q.factor()
         c3 = cfg.get("c", 1)

@@ -30,12 +30,16 @@ def _free_port():
     return p
 
 
-def _launch(world, cfg, timeout=600):
+def _launch(world, cfg, timeout=600, multipath=True):
+    """multipath: grids of pairs (2x2x1, 2x2x2) send every pair broadcast / depth all-reduce / partner exchange through
+    capi_pairs_transfer with a threshold of 8 doubles, so the relayed two-phase path (csrc/pair_paths.h) carries even these small
+    messages; False = the per-pair collectives on the sub-communicators."""
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   OMP_NUM_THREADS="1", GLOO_SOCKET_IFNAME="lo", CAPITAL_MIN_CHUNK_COLS="8")
+                   OMP_NUM_THREADS="1", GLOO_SOCKET_IFNAME="lo", CAPITAL_MIN_CHUNK_COLS="8",
+                   CAPITAL_MULTIPATH="1" if multipath else "0", CAPITAL_MULTIPATH_MIN="8")
         procs.append(subprocess.Popen([sys.executable, os.path.join(SHIM, "rank_main.py"), json.dumps(cfg)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -63,13 +67,19 @@ def _launch(world, cfg, timeout=600):
     (8, 2, 128, -1, 1, False, 0),
     (8, 2, 192, -2, 0, True, 2),
     (8, 2, 130, 0, 1, True, 3),
+    (8, 2, 192, -2, 1, False, (1, 4)),   # complete_inv = 1: the right-TRMM SUMMAs of the inverse completion in the chunk pipeline too
+    (8, 2, 200, -2, 1, True, (3, 3)),
+    (8, 2, 192, -2, 1, True, (0, 3, "plain")),   # the same pipeline over the per-pair RCCL collectives (multi-path off)
+    (4, 1, 128, -1, 1, False, (0, 0, "plain")),
 ])
 def test_cholinv_on_grids(oracle, shim_lib, world, c, n, bc, ci, serialize, policy):
-    chunks = 0
+    chunks, multipath = 0, True
     if isinstance(policy, tuple):
-        policy, chunks = policy
+        multipath = len(policy) < 3
+        policy, chunks = policy[0], policy[1]
     with tempfile.TemporaryDirectory() as d:
-        _launch(world, {"kind": "cholinv", "n": n, "c": c, "bc": bc, "ci": ci, "serialize": serialize, "policy": policy, "chunks": chunks, "dir": d})
+        _launch(world, {"kind": "cholinv", "n": n, "c": c, "bc": bc, "ci": ci, "serialize": serialize, "policy": policy, "chunks": chunks, "dir": d},
+                multipath=multipath)
         A = oracle.distribute_symmetric(n, n, 0, 0, 1, 1)
         Rg, Ig = np.zeros((n, n), order="F"), np.zeros((n, n), order="F")
         levels = set()
@@ -170,16 +180,19 @@ def test_cacqr_1d_sharded_rows(oracle, shim_lib, world, m, n, variant, serialize
         assert np.abs(Qg - Qref).max() <= 1e-12 * (1 if variant == 2 else 100)
 
 
-@pytest.mark.parametrize("m,n,variant,serialize,bc,ci", [(512, 32, 2, False, 0, 1), (1000, 48, 2, True, -1, 1), (512, 32, 1, False, 0, 1),
-                                                         (512, 32, 2, False, -1, 0), (1000, 48, 1, True, -1, 0)])
-def test_cacqr_3d_cubic_grid(oracle, shim_lib, m, n, variant, serialize, bc, ci):
+@pytest.mark.parametrize("m,n,variant,serialize,bc,ci,chunks", [(512, 32, 2, False, 0, 1, 0), (1000, 48, 2, True, -1, 1, 0), (512, 32, 1, False, 0, 1, 0),
+                                                                (512, 32, 2, False, -1, 0, 0), (1000, 48, 1, True, -1, 0, 0),
+                                                                (1000, 64, 2, False, -1, 1, 3),      # right-TRMM SUMMA in the chunk pipeline
+                                                                (1024, 64, 2, True, -1, 0, 4)])      # ... and the blocked solve's gemm
+def test_cacqr_3d_cubic_grid(oracle, shim_lib, m, n, variant, serialize, bc, ci, chunks):
     """c == d == 2 on 8 ranks (cacqr.hpp:75-116,195-215): Gram by Bcast(row)+gemm+Reduce(column)+Bcast(depth), distributed
     cholinv on the Gram matrix, Q = Q R^-1 by a right-TRMM SUMMA -- or, with complete_inv = 0 (ci), by the blocked solve
     Q1 = A1 R11^-1, Q2 = (A2 - Q1 R12) R22^-1 (cacqr.hpp:44-73).  Q and R are unique, so the assembled result must equal the
     1-D oracle on the assembled input."""
     world, c, d = 8, 2, 2
     with tempfile.TemporaryDirectory() as dd:
-        _launch(world, {"kind": "cacqr", "m": m, "n": n, "c": c, "variant": variant, "serialize": serialize, "ci": ci, "bc": bc, "dir": dd})
+        _launch(world, {"kind": "cacqr", "m": m, "n": n, "c": c, "variant": variant, "serialize": serialize, "ci": ci, "bc": bc, "chunks": chunks,
+                        "dir": dd})
         Ag, Qg, Rg = np.zeros((m, n), order="F"), np.zeros((m, n), order="F"), np.zeros((n, n), order="F")
         for r in range(world):
             z = np.load(os.path.join(dd, f"rank{r}.npz"))

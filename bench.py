@@ -112,7 +112,9 @@ def recorded_traffic(n, gpus):
     return tot / launches, f"recorded: profiles/{tag.format('{fe,wr}')}: 2 x FETCH_SIZE + WRITE_SIZE, mean of the {launches} launches of one factor()"
 
 
-def time_cholesky(driver, L, h, n, c, bc, chunks, steps, warmup, distributed, device, bc_policy, trsm_mode=False):
+def time_cholesky(driver, L, h, n, c, bc, chunks, steps, warmup, distributed, device, bc_policy, trsm_mode=False, multipath=None):
+    if multipath is not None:          # read by topo::square when the grid object is built (capital_amd/src/util/topology.h)
+        os.environ["CAPITAL_MULTIPATH"] = "1" if multipath else "0"
     prob = driver.Cholinv(n, c=c, complete_inv=0, split=1, bc_mult=bc, layout=0, num_chunks=chunks, serialize=True, bc_policy=bc_policy, trsm_mode=trsm_mode)
     prob.generate()
     for _ in range(warmup):
@@ -153,6 +155,34 @@ def time_cacqr2(driver, m, n, reps, distributed, device):
     dt = max_over_ranks(time.perf_counter() - t0, distributed, device) / reps
     out = {"tflops": 4.0 * m * n * n / dt / 1e12, "ms": dt * 1e3, "residual": q.residual(), "orthogonality": q.orthogonality(), "m_loc": q.m_loc}
     q.close()
+    return out
+
+
+def make_line(args, n, bc, r, chunks, multipath, rccl, residual_max, comm_forms, traffic_rec):
+    """the one JSON line (without the extras that main() appends) for a timed Cholesky result `r`"""
+    traffic, traffic_src = traffic_rec
+    k = r["kernel"]
+    achieved = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
+
+    out = {
+        "metric": "TFLOP/s (whole node) Cholesky n=65536, algorithmic n^3/3, recursive cholinv factor(), inputs resident in HBM",
+        "value": r["tflops"], "unit": "TFLOP/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"n={n} recursive Cholesky with inverse (cholinv, complete_inv=0, split=1, bc_mult={bc}) on a "
+                               f"{r['grid'][0]}x{r['grid'][1]}x{r['grid'][2]} GPU grid" + (" = BASELINE config 4" if args.gpus == 8 and n == 65536 else ""),
+                   "n": n, "grid": r["grid"], "base_case_order": r["stats"]["bc_dimension"], "residual": residual_max,
+                   "residual_is": "max over ranks of the reference validator (test/cholesky/validate.hpp:7-49)", "summa_chunks": chunks,
+                   "multipath_pair_transfers": bool(multipath), "comm_forms": comm_forms,
+                   "rccl_world": list(rccl) if rccl else None},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": "dgemm_tile_kernel<128,true,true> (trailing update + R12 solve, orders >= 4096)",
+                     "launches_per_step": k["launches"] / max(args.steps, 1),
+                     "avg_launch_ms": k["ms"] / max(k["launches"], 1), "max_launch_ms": k["max_ms"],
+                     "avg_flops_per_launch": k["flops"] / max(k["launches"], 1),
+                     "tile_kernel_share_of_step": k["all_tile_ms"] / (r["ms_per_step"] * args.steps) if r["ms_per_step"] > 0 else None},
+    }
     return out
 
 
@@ -218,33 +248,57 @@ def main():
     c = GRID_C[args.gpus]
     d = int(round((args.gpus // c) ** 0.5))
     bc = args.bc if args.bc is not None else bc_mult_for(n, d, c, BASE_CASE_ORDER)
-    # num_chunks > 0 turns on the chunked SUMMA pipeline (collectives on a second HIP stream beside the tile kernel).
-    # Off by default until the plain path has been seen to run on a multi-GPU node.
-    chunks = int(os.environ.get("CAPITAL_BENCH_CHUNKS", "0")) if distributed else 0
-    r = time_cholesky(driver, L, h, n, c, bc, chunks, args.steps, args.warmup, distributed, device, bc_policy=0 if distributed else 2)
-    residual_max = max_over_ranks(r["residual"], distributed, device)
-    k = r["kernel"]
-    achieved = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
-    traffic, traffic_src = recorded_traffic(n, args.gpus)
+    # N > 1: how the grid communicates is chosen ON THIS NODE, by measurement.  The plain form -- one RCCL call per
+    # pair collective, no overlap -- is timed first, in full (W + K steps): from then on a valid line exists.  Then every other form
+    # (multi-path pair transfers over all xGMI links, the chunked SUMMA pipeline on a second stream, both) gets one warm-up and one timed
+    # step; the fastest one that validates (residual <= 1e-14) and beats the plain form by > 2 % is timed in full and reported, with the
+    # whole table in `config.comm_forms`.  CAPITAL_BENCH_FORM=<name> pins a form (no probing); CAPITAL_BENCH_CHUNKS=<k> pins the pipeline
+    # depth of the plain form as before.  If a probe does not come back within CAPITAL_BENCH_PROBE_S (default 300 s), rank 0 prints the
+    # plain form's line and every rank leaves: a new code path must not cost the node's number.
+    forms = [("plain", int(os.environ.get("CAPITAL_BENCH_CHUNKS", "0")), False)]
+    if distributed and "CAPITAL_BENCH_CHUNKS" not in os.environ:
+        forms += [("chunks4", 4, False), ("chunks8", 8, False)]
+        if args.gpus >= 4:
+            forms += [("multipath", 0, True), ("multipath+chunks4", 4, True), ("multipath+chunks8", 8, True)]
+    pinned = os.environ.get("CAPITAL_BENCH_FORM")
+    if pinned:
+        forms = [f for f in forms if f[0] == pinned] or forms[:1]
+    name, chunks, mp = forms[0]
+    r = time_cholesky(driver, L, h, n, c, bc, chunks, args.steps, args.warmup, distributed, device, bc_policy=0 if distributed else 2,
+                      multipath=mp if distributed else None)
+    comm_forms = [{"form": name, "chunks": chunks, "multipath": mp, "ms_per_step": r["ms_per_step"], "residual": r["residual"], "timed": "full"}]
+    if len(forms) > 1:
+        import threading
+        safe_line = json.dumps(make_line(args, n, bc, r, chunks, mp, rccl, max_over_ranks(r["residual"], distributed, device), comm_forms,
+                                         recorded_traffic(n, args.gpus)))
 
-    out = {
-        "metric": "TFLOP/s (whole node) Cholesky n=65536, algorithmic n^3/3, recursive cholinv factor(), inputs resident in HBM",
-        "value": r["tflops"], "unit": "TFLOP/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"n={n} recursive Cholesky with inverse (cholinv, complete_inv=0, split=1, bc_mult={bc}) on a "
-                               f"{r['grid'][0]}x{r['grid'][1]}x{r['grid'][2]} GPU grid" + (" = BASELINE config 4" if args.gpus == 8 and n == 65536 else ""),
-                   "n": n, "grid": r["grid"], "base_case_order": r["stats"]["bc_dimension"], "residual": residual_max,
-                   "residual_is": "max over ranks of the reference validator (test/cholesky/validate.hpp:7-49)", "summa_chunks": chunks,
-                   "rccl_world": list(rccl) if rccl else None},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": "dgemm_tile_kernel<128,true,true> (trailing update + R12 solve, orders >= 4096)",
-                     "launches_per_step": k["launches"] / max(args.steps, 1),
-                     "avg_launch_ms": k["ms"] / max(k["launches"], 1), "max_launch_ms": k["max_ms"],
-                     "avg_flops_per_launch": k["flops"] / max(k["launches"], 1),
-                     "tile_kernel_share_of_step": k["all_tile_ms"] / (r["ms_per_step"] * args.steps) if r["ms_per_step"] > 0 else None},
-    }
+        def bail():      # a probe hangs: the line that exists goes out, everybody leaves (exit 0: the measurement of the plain form is valid)
+            if rank == 0:
+                print(safe_line, flush=True)
+            sys.stderr.write(f"bench.py: rank {rank}: a communication-form probe did not return; reporting the plain form\n")
+            sys.stderr.flush()
+            os._exit(0)
+        timer = threading.Timer(float(os.environ.get("CAPITAL_BENCH_PROBE_S", "300")), bail)
+        timer.daemon = True
+        timer.start()
+        best = None
+        for fname, fch, fmp in forms[1:]:
+            try:
+                pr = time_cholesky(driver, L, h, n, c, bc, fch, 1, 1, distributed, device, bc_policy=0, multipath=fmp)
+                ok = max_over_ranks(pr["residual"], distributed, device) <= 1e-14
+                comm_forms.append({"form": fname, "chunks": fch, "multipath": fmp, "ms_per_step": pr["ms_per_step"], "residual": pr["residual"],
+                                   "timed": "1 step", "valid": ok})
+                if ok and (best is None or pr["ms_per_step"] < best[3]):
+                    best = (fname, fch, fmp, pr["ms_per_step"])
+            except Exception as e:           # (a driver error raises on every rank alike: the grid agrees on status words)
+                comm_forms.append({"form": fname, "chunks": fch, "multipath": fmp, "error": repr(e)[:200]})
+        if best is not None and best[3] < 0.98 * r["ms_per_step"]:
+            name, chunks, mp = best[:3]
+            r = time_cholesky(driver, L, h, n, c, bc, chunks, args.steps, args.warmup, distributed, device, bc_policy=0, multipath=mp)
+            comm_forms.append({"form": name, "chunks": chunks, "multipath": mp, "ms_per_step": r["ms_per_step"], "residual": r["residual"], "timed": "full"})
+        timer.cancel()
+    residual_max = max_over_ranks(r["residual"], distributed, device)
+    out = make_line(args, n, bc, r, chunks, mp, rccl, residual_max, comm_forms if distributed else None, recorded_traffic(n, args.gpus))
 
     if args.gpus == 1 and not args.no_config2 and not args.n:
         n2 = 32768

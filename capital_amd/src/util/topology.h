@@ -61,8 +61,9 @@ public:
     // Multi-path pair transfers (capi_pairs_transfer): on a grid whose rows / columns (d == 2) or depth fibres (c == 2) are PAIRS,
     // the pair collectives of SUMMA are issued by ALL ranks of `comm` together and cut over every link of the node's mesh instead
     // of one link per pair.  Needs ranks that can relay (size >= 4).  CAPITAL_MULTIPATH=0 keeps the per-pair RCCL calls.
+    // (CAPITAL_MULTIPATH=2 also takes the pair algorithms on a 2-rank grid, where nothing can relay: rehearsal of the depth halves)
     const char* mp = getenv("CAPITAL_MULTIPATH");
-    multipath = size >= 4 && (d == 2 || c == 2) && !(mp && atoi(mp) == 0);
+    multipath = size >= ((mp && atoi(mp) >= 2) ? 2 : 4) && (d == 2 || c == 2) && !(mp && atoi(mp) == 0);
   }
   square(const square&) = delete;
   square& operator=(const square&) = delete;

@@ -25,6 +25,9 @@ def main():
     assert (rr, rs) == (rank, world), f"RCCL reports rank/size {(rr, rs)}, launcher {(rank, world)}"
     for case in cfg["cases"]:
         tag = case["tag"]
+        for k in ("CAPITAL_MULTIPATH", "CAPITAL_MULTIPATH_MIN"):       # per-case switches, read when the grid object is built
+            os.environ.pop(k, None)
+        os.environ.update(case.get("env", {}))
         if case["kind"] == "cholinv":
             p = driver.Cholinv(case["n"], c=case["c"], complete_inv=case["ci"], split=1, bc_mult=case["bc"], layout=case.get("layout", 0),
                                num_chunks=case.get("chunks", 0), serialize=case["serialize"], bc_policy=case["policy"])
@@ -37,7 +40,7 @@ def main():
             p.close()
         else:
             q = driver.Cacqr(case["m"], case["n"], c=case.get("c", 1), variant=2, complete_inv=case.get("ci", 0), bc_mult=case.get("bc", 0),
-                             serialize=case["serialize"])
+                             num_chunks=case.get("chunks", 0), serialize=case["serialize"])
             q.generate()
             q.factor()
             c3 = case.get("c", 1)

@@ -115,7 +115,7 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from capital_amd import driver
-    lib = C.CDLL(os.path.join(HERE, "libcapital_driver_cpu.so"), mode=C.RTLD_GLOBAL)
+    lib = C.CDLL(os.environ.get("CAPITAL_SHIM_LIB", os.path.join(HERE, "libcapital_driver_cpu.so")), mode=C.RTLD_GLOBAL)   # (override: the sanitizer build)
     driver.bind(lib)
     driver._drv = lib                      # the driver classes now talk to the CPU-shim build
     keep = make_callback()

@@ -1,4 +1,5 @@
-"""BASELINE configs 2 and 3 at FULL size (n = 32768 recursive Cholesky; CA-CholeskyQR2 m = 2^22, n = 256) and the per-GPU slice
+"""BASELINE configs 2 and 3 at FULL size (n = 32768 recursive Cholesky; CA-CholeskyQR2 m = 2^22, n = 256), the metric's own matrix
+(n = 65536 on one GPU) and the per-GPU slice
 of config 5 (CA-CholeskyQR2 on 2^23 x 1024: what each of the 8 GPUs holds of m = 2^26), checked through
 size-independent properties -- the oracle cannot reach these sizes in test time:
   * the reference's own validators (test/cholesky/validate.hpp, test/qr/validate.hpp) at the tolerances of SURVEY.md 8c
@@ -44,6 +45,47 @@ def test_cholinv_config2_full_size_properties(drv):
     # diagonal of R^T R reproduces diag(A) = n + U[0,1): cheap independent look at the factor itself
     d = (R * R).sum(dim=0)
     assert ((d >= n - 1e-6) & (d <= n + 1 + 1e-6)).all()
+
+
+@pytest.mark.gpu
+def test_cholinv_n65536_properties(drv):
+    """The headline's own matrix (BASELINE `metric`: Cholesky n = 65536; on ONE MI355X: 139 GiB with both factors and their packed
+    copies), through properties only: the reference's validator, structure, the diagonal of R^T R, and the inverse round trip
+    R_ii R^-1_ii = I on both diagonal halves in 16384-blocks (diagonal blocks = I, the off-diagonal block R_aa X_ab + R_ab X_bb = 0)."""
+    import torch
+    n, h, b = 65536, 32768, 16384
+    prob = drv.Cholinv(n, c=1, complete_inv=0, split=1, bc_mult=-6, serialize=True, bc_policy=2)
+    prob.generate()
+    prob.factor()
+    drv.sync()
+    st = prob.stats()
+    assert st["bc_dimension"] == 1024
+    res = prob.residual()
+    assert res <= 1e-14, res                                          # ||A - R^T R||_F / ||A||_F (test/cholesky/validate.hpp:7-49)
+    R = torch.from_numpy(prob.R()).cuda()
+    Ri = torch.from_numpy(prob.Rinv()).cuda()
+    prob.close()
+    from capital_amd import capi
+    capi.load().capi_trim_workspaces(drv.handle_ptr())                # the arena is gone with `prob`; this frees the kernels' own scratch
+    assert (torch.diagonal(R) > 0).all() and (torch.diagonal(Ri) > 0).all()
+    for k in range(0, n, b):                                          # strictly-lower parts are exactly zero (block by block: no n x n temporaries)
+        assert torch.count_nonzero(torch.tril(R[k:k + b, k:k + b], -1)).item() == 0
+        assert torch.count_nonzero(torch.tril(Ri[k:k + b, k:k + b], -1)).item() == 0
+        if k:
+            assert torch.count_nonzero(R[k:k + b, :k]).item() == 0 and torch.count_nonzero(Ri[k:k + b, :k]).item() == 0
+    assert torch.count_nonzero(Ri[:h, h:]).item() == 0                # top-level R^-1_12 is not completed (complete_inv = 0)
+    d = torch.zeros(n, dtype=torch.float64, device="cuda")
+    for k in range(0, n, b):
+        d[k:k + b] = (R[:k + b, k:k + b] * R[:k + b, k:k + b]).sum(dim=0)
+    assert ((d >= n - 1e-6) & (d <= n + 1 + 1e-6)).all()              # diag(R^T R) = diag(A) = n + U[0,1)
+    eye = torch.eye(b, dtype=torch.float64, device="cuda")
+    for o in (0, h):
+        a0, a1, b0, b1 = o, o + b, o + b, o + 2 * b
+        assert (R[a0:a1, a0:a1] @ Ri[a0:a1, a0:a1] - eye).abs().max().item() <= 1e-11
+        assert (R[b0:b1, b0:b1] @ Ri[b0:b1, b0:b1] - eye).abs().max().item() <= 1e-11
+        off = R[a0:a1, a0:a1] @ Ri[a0:a1, b0:b1] + R[a0:a1, b0:b1] @ Ri[b0:b1, b0:b1]
+        assert off.abs().max().item() <= 1e-11
+        del off
 
 
 @pytest.mark.gpu

@@ -82,10 +82,20 @@ def test_cholinv_and_cacqr2_on_rccl(oracle, world, loopback):
         {"tag": "ch_p3", "kind": "cholinv", "n": n, "c": c, "bc": -2, "ci": 1, "serialize": True, "policy": 3},
         {"tag": "ch_p1", "kind": "cholinv", "n": n, "c": c, "bc": -3, "ci": 1, "serialize": False, "policy": 1},
         {"tag": "ch_chunks", "kind": "cholinv", "n": n, "c": c, "bc": -3, "ci": 1, "serialize": True, "policy": 0, "chunks": 3},
+        # multi-path pair transfers (csrc/pair_paths.h) with a low threshold, so that broadcasts, exchanges and depth halves of these
+        # orders are cut into units and relayed; "=2" also runs the depth-pair algorithm on the 2-rank grid; then the chunk pipeline on top
+        {"tag": "ch_mp", "kind": "cholinv", "n": n, "c": c, "bc": -3, "ci": 1, "serialize": True, "policy": 0,
+         "env": {"CAPITAL_MULTIPATH": "2", "CAPITAL_MULTIPATH_MIN": "4096"}},
+        {"tag": "ch_mp_chunks", "kind": "cholinv", "n": n + 40, "c": c, "bc": -3, "ci": 1, "serialize": False, "policy": 2, "chunks": 4,
+         "env": {"CAPITAL_MULTIPATH": "2", "CAPITAL_MULTIPATH_MIN": "4096"}},
+        {"tag": "ch_plain_chunks", "kind": "cholinv", "n": n, "c": c, "bc": -3, "ci": 1, "serialize": True, "policy": 0, "chunks": 3,
+         "env": {"CAPITAL_MULTIPATH": "0"}},
         {"tag": "qr", "kind": "cacqr", "m": m_loc * world, "n": nq, "serialize": True},
     ]
     if world == 8:
         cases.append({"tag": "qr3d", "kind": "cacqr", "m": 1 << 14, "n": 512, "c": 2, "ci": 1, "bc": -1, "serialize": False})
+        cases.append({"tag": "qr3d_chunks", "kind": "cacqr", "m": 1 << 14, "n": 512, "c": 2, "ci": 0, "bc": -1, "serialize": False, "chunks": 3,
+                      "env": {"CAPITAL_MULTIPATH_MIN": "4096"}})
         cases.append({"tag": "ch_l1", "kind": "cholinv", "n": n, "c": c, "bc": -3, "ci": 1, "serialize": False, "policy": 0, "layout": 1})
     with tempfile.TemporaryDirectory() as d:
         _launch(world, {"dir": d, "cases": cases}, loopback=loopback)

@@ -39,7 +39,7 @@ def _launch(world, cfg, timeout=600, multipath=True):
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    OMP_NUM_THREADS="1", GLOO_SOCKET_IFNAME="lo", CAPITAL_MIN_CHUNK_COLS="8",
-                   CAPITAL_MULTIPATH="1" if multipath else "0", CAPITAL_MULTIPATH_MIN="8")
+                   CAPITAL_MULTIPATH="2" if multipath else "0", CAPITAL_MULTIPATH_MIN="8")
         procs.append(subprocess.Popen([sys.executable, os.path.join(SHIM, "rank_main.py"), json.dumps(cfg)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []

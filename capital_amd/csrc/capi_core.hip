@@ -257,17 +257,35 @@ int capi_range_pop(void) {
 
 }  // extern "C"
 
+// A captured launch chain (factor_f64.hip: CAPI_GRAPH) has the workspace pointers of its launches baked in -- the primary block's
+// split-K slabs, ws2 / ws3 scratch -- and the profile / kernel-choice state of the day it was captured: when any workspace block
+// moves or is released, every captured chain of the handle is dropped and re-captured on its next use.
+static void graphs_invalidate(capi_handle_t h) {
+  for (int i = 0; i < h->graphs_n; ++i) if (h->graphs[i].exec) (void)hipGraphExecDestroy(h->graphs[i].exec);
+  h->graphs_n = 0;
+}
+
 static int ws_grow(capi_handle_t h, void** slot, size_t* cap, size_t bytes, void** p) {
   if (!h || !p) return CAPI_EINVAL;
   if (bytes > *cap) {
+    graphs_invalidate(h);
     // stream-ordered users of the old block must finish before it is released
     CAPI_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     if (*slot) CAPI_HIP_CHECK(h, hipFree(*slot));
     *slot = nullptr;
     *cap = 0;
     size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
-    hipError_t e = hipMalloc(slot, want);
-    if (e == hipErrorOutOfMemory) { snprintf(h->err, sizeof(h->err), "workspace hipMalloc(%zu) out of memory", want); return CAPI_ENOMEM; }
+    // CAPI_WS_CAP_MB (diagnostics / tests): requests above it fail as an out-of-memory hipMalloc would -- the fallback paths behind
+    // CAPI_ENOMEM can then be exercised without exhausting 288 GB
+    const char* cap_mb = getenv("CAPI_WS_CAP_MB");
+    hipError_t e = (cap_mb && want > ((size_t)atoll(cap_mb) << 20)) ? hipErrorOutOfMemory : hipMalloc(slot, want);
+    if (e == hipErrorOutOfMemory) {
+      // callers with a slower path that needs no workspace (qr_f64.hip: the Householder panels behind the tall-panel routines) go on after
+      // this status: HIP's sticky last-error must not be what their next hipGetLastError() check sees
+      (void)hipGetLastError();
+      snprintf(h->err, sizeof(h->err), "workspace hipMalloc(%zu) out of memory", want);
+      return CAPI_ENOMEM;
+    }
     CAPI_HIP_CHECK(h, e);
     *cap = want;
   }
@@ -285,6 +303,7 @@ extern "C" int capi_trim_workspaces(capi_handle_t h) {
   CAPI_HIP_CHECK(h, hipSetDevice(h->device));
   int rc = capi_sync(h);
   if (rc != CAPI_OK) return rc;
+  graphs_invalidate(h);
   for (int i = 0; i < capi_handle_s::NSTREAMS; ++i) {
     void** blocks[4] = {&h->ws[i], &h->ws2[i], &h->ws3[i], &h->ws4[i]};
     size_t* sizes[4] = {&h->ws_bytes[i], &h->ws2_bytes[i], &h->ws3_bytes[i], &h->ws4_bytes[i]};

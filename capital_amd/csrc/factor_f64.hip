@@ -705,7 +705,7 @@ int capi_dpotrf_trtri(capi_handle_t h, int64_t n, double* A, int64_t lda, double
   // block comes by (same pointers, order and scratch: the next factor() of the same matrix) the chain is captured into a hipGraph,
   // from the third on it is replayed -- one submission instead of ~50 per order-1024 block.  (CAPI_GRAPH=1; off by default.)
   static const int graph_mode = getenv("CAPI_GRAPH") ? atoi(getenv("CAPI_GRAPH")) : 0;
-  if (!graph_mode || !blocked || n > 2048) return run();
+  if (!graph_mode || !blocked || n > 2048 || h->prof_on) return run();      // (a replay records no per-launch events: profiled runs launch plainly)
   capi_handle_s::graph_ent* e = nullptr;
   for (int i = 0; i < h->graphs_n; ++i) {
     auto& g = h->graphs[i];

@@ -204,3 +204,36 @@ def test_diagonal_block_routine_replayed_from_a_graph():
     assert len(vals) == 2
     for a, b in vals:
         assert float(a) <= 1e-14 and float(b) <= 1e-13
+
+
+@pytest.mark.gpu
+def test_geqrf_tall_without_workspace_takes_the_householder_panels(hip, oracle, monkeypatch):
+    """The tall-panel routines ask the handle for 2 m n doubles; when that allocation fails (here: CAPI_WS_CAP_MB makes requests above
+    8 MiB fail the way an out-of-memory hipMalloc does) geqrf must fall back to the column-by-column panels, which need
+    none of it -- not return the allocator's stale error -- and still give LAPACK's factorisation."""
+    import torch
+    from capital_amd import capi
+    m, n = 16384, 64                                              # 2 m n doubles = 16 MiB: above the cap; every other block stays below it
+    rng = np.random.default_rng(99)
+    A = np.asfortranarray(rng.random((m, n)) - 0.5)
+    ref = A.copy(order="F")
+    tau_ref = oracle.dgeqrf(ref)
+    h2 = capi.Handle(0)                                           # a fresh handle: nothing cached from earlier tests
+    dA = capi.to_device(A)
+    dtau = torch.zeros(n, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    monkeypatch.setenv("CAPI_WS_CAP_MB", "8")
+    h2.call("capi_dgeqrf", m, n, capi.ptr(dA), m, capi.ptr(dtau))
+    h2.sync()
+    out = capi.to_host(dA)
+    assert np.abs(np.triu(out[:n]) - np.triu(ref[:n])).max() <= 1e-12 * np.abs(np.triu(ref[:n])).max()
+    assert np.abs(np.tril(out, -1) - np.tril(ref, -1)).max() <= 1e-12
+    assert np.abs(dtau.cpu().numpy() - tau_ref).max() <= 1e-12
+    # (orgqr's one-block path asks for LESS than the panels behind it need at this shape -- 8.5 against 13.6 MB -- so no cap separates
+    #  them: its fallback cannot be reached by a failing allocation that the slow path would survive)
+    monkeypatch.delenv("CAPI_WS_CAP_MB")
+    h2.call("capi_dorgqr", m, n, n, capi.ptr(dA), m, capi.ptr(dtau))
+    h2.sync()
+    Q = capi.to_host(dA)
+    assert np.abs(Q.T @ Q - np.eye(n)).max() <= 1e-13
+    assert np.abs(Q @ np.triu(out[:n]) - A).max() <= 1e-13 * n

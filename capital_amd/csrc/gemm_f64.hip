@@ -1503,11 +1503,13 @@ __global__ __launch_bounds__(TSK_THREADS, 1) void trmm_right_ts32_kernel(const G
   }
 }
 
-// (A third form that fetched the next tile with global_load_lds_dwordx4 -- no staging registers, no ds_write pass -- and
-//  spread the previous tile's stores over the MFMA loop measured 5.95 ms against 5.21 ms for the register-staged kernel
-//  above, with or without the interleaved stores.  With the stores compiled out the kernel runs at 64.8 TFLOP/s instead of
-//  47: reading and writing 256 column streams 8 lda bytes apart, 256 bytes at a time, it moves 3.3 TB/s where a plain copy
-//  of the same 8 GiB reaches 4.96 TB/s, and the MFMA work alone takes 4.1 ms -- both limits are close.)
+// (LDS-DMA forms of this kernel -- global_load_lds_dwordx4, no staging registers, no ds_write pass -- were built twice and measured slower
+//  both times.  Round 1: DMA one tile ahead, the previous tile's stores spread over the MFMA loop: 5.95 against 5.21 ms.  Round 3: the fetch
+//  issued from inline assembly (through the builtin the compiler, unable to tell the two buffers apart, waits with vmcnt(0) for the fetch it
+//  has just issued), TWO tiles ahead on the two buffers -- MFMA(t) | vmcnt(0) | barrier | DMA(t + 2) | stores(t) --, natural [column][32 rows]
+//  LDS image read with one ds_read_b128 per k-step; parity-green, 254 VGPRs, no spills, and 5.55 / 5.26 / 5.30 / 4.96 ms against 4.90 / 4.64 /
+//  4.83 / 4.46 for the register-staged kernel above (cm->cm / cm->p32 / p32->cm / p32->p32, same process order, min = median to 1 %:
+//  profiles/r3h_ts32_dma_ab.log).  With the stores compiled out the register kernel runs at 64.8 TFLOP/s, its MFMA work alone takes 4.1 ms.)
 __global__ __launch_bounds__(TSK_THREADS, 1) void trmm_right_ts_kernel(const GemmArgs p) {   // N == K == 256
   extern __shared__ __attribute__((aligned(16))) double lds[];
   switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {

@@ -13,7 +13,7 @@ The matrix is the metric's own, n = 65536, at EVERY N (strong scaling): N = 1 ho
 both factors and the packed copies), N = 8 is BASELINE config 4 (2 x 2 x 2 grid).
 The same JSON line also carries
   * `config2`: n = 32768 on one GPU (BASELINE config 2), N = 1 only;
-  * `cholesky_trsm_mode`: n = 65536 without forming any inverse (not the reference's schedule; an extra), N = 1 only;
+  * `cholesky_trsm_mode`: n = 65536 without forming any inverse (not the reference's schedule; an extra), at every N;
   * `cacqr2`: CA-CholeskyQR2 on m = 2^22 x 256 (BASELINE config 3), N = 1 only;
   * `cacqr2_config5`: CA-CholeskyQR2 with the per-GPU slice of BASELINE config 5, 2^23 x 1024 on every GPU (m = 2^23 N:
     weak in m; N = 8 IS config 5, m = 2^26), 4 m n^2 flops;
@@ -317,6 +317,17 @@ def main():
         rt = time_cholesky(driver, L, h, n, 1, bc, 0, 2, 1, False, device, bc_policy=2, trsm_mode=True)
         out["cholesky_trsm_mode"] = {"workload": f"n={n} Cholesky, TRSM mode (R only, no inverse formed), 1 GPU", "tflops": rt["tflops"],
                                      "ms_per_step": rt["ms_per_step"], "residual": rt["residual"]}
+
+    if distributed and not args.no_config2 and not os.environ.get("CAPITAL_BENCH_NO_TRSM_GRID"):
+        # NOT the headline: TRSM mode on the grid (cholinv.h: potrf_rec_grid; d == 1: every layer factors the replicated matrix) -- an extra;
+        # its failure must not take the line with it (a driver error raises on every rank alike)
+        try:
+            rt = time_cholesky(driver, L, h, n, c, bc, 0, 2, 1, distributed, device, bc_policy=0, trsm_mode=True, multipath=mp)
+            out["cholesky_trsm_mode"] = {"workload": f"n={n} Cholesky, TRSM mode (R only, no inverse formed) on the {rt['grid'][0]}x{rt['grid'][1]}x{rt['grid'][2]} grid",
+                                         "tflops": rt["tflops"], "ms_per_step": rt["ms_per_step"],
+                                         "residual": max_over_ranks(rt["residual"], distributed, device)}
+        except Exception as e:
+            out["cholesky_trsm_mode"] = {"error": repr(e)[:300]}
 
     if not args.no_qr:
         reps = max(args.steps, 3)

@@ -45,6 +45,7 @@ _SIGS = {
     "capi_daxpby": [_i64, _dbl, _vp, _vp],
     "capi_remove_triangle": [C.c_char, _vp, _i64, _i64, _i64, _i64, _i64],
     "capi_block_to_cyclic": [_vp, _vp, _i64, _i64, _i64],
+    "capi_block_to_cyclic_full": [_vp, _vp, _i64, _i64, _i64],
     "capi_cyclic_to_block": [_vp, _vp, _i64, _i64, _i64],
     "capi_block_to_cyclic_tri": [_vp, _vp, _i64, _i64],
     "capi_cyclic_to_block_tri": [_vp, _vp, _i64, _i64],
@@ -137,7 +138,7 @@ def declared_symbols():
     import re
     hdr = os.path.join(os.path.dirname(_HERE), "include", "capital_hip.h")
     txt = open(hdr).read()
-    return sorted(set(re.findall(r"^(?:int|void\*|const char\*)\s+(capi_[a-z0-9_]+)\s*\(", txt, re.M)))
+    return sorted(set(re.findall(r"^(?:int|int64_t|void\*|const char\*)\s+(capi_[a-z0-9_]+)\s*\(", txt, re.M)))
 
 
 def ptr(t):

@@ -107,7 +107,8 @@ __global__ void block_cyclic_kernel(int to_cyclic, double* __restrict__ blocked,
   for (int64_t gcol = blockIdx.y; gcol < cg; gcol += gridDim.y) {
     const int64_t i = gcol / d, x = gcol % d, k = grow / d, y = grow % d;
     const int64_t b = (y * d + x) * rl * cl + i * rl + k;
-    if (to_cyclic) cyclic[gcol * rg + grow] = (grow > gcol) ? 0.0 : blocked[b];
+    if (to_cyclic == 2) cyclic[gcol * rg + grow] = blocked[b];                     // an off-diagonal aggregate: nothing is zeroed
+    else if (to_cyclic) cyclic[gcol * rg + grow] = (grow > gcol) ? 0.0 : blocked[b];
     else blocked[b] = cyclic[gcol * rg + grow];
   }
 }
@@ -342,6 +343,13 @@ int capi_block_to_cyclic(capi_handle_t h, const double* blocked, double* cyclic,
   CAPI_HIP_CHECK(h, hipGetLastError());
   return CAPI_OK;
 }
+int capi_block_to_cyclic_full(capi_handle_t h, const double* blocked, double* cyclic, int64_t rl, int64_t cl, int64_t d) {
+  CAPI_REQUIRE(h, h && blocked && cyclic && rl > 0 && cl > 0 && d > 0, "args");
+  hipLaunchKernelGGL(block_cyclic_kernel, grid2(rl * d, cl * d), dim3(256), 0, h->stream, 2, (double*)blocked, cyclic, rl, cl, d);
+  CAPI_HIP_CHECK(h, hipGetLastError());
+  return CAPI_OK;
+}
+
 int capi_cyclic_to_block(capi_handle_t h, double* blocked, const double* cyclic, int64_t rl, int64_t cl, int64_t d) {
   CAPI_REQUIRE(h, h && blocked && cyclic && rl > 0 && cl > 0 && d > 0, "args");
   hipLaunchKernelGGL(block_cyclic_kernel, grid2(rl * d, cl * d), dim3(256), 0, h->stream, 0, blocked, (double*)cyclic, rl, cl, d);

@@ -179,7 +179,7 @@ int capital_cholinv_residual(void* p, double* out) { return guarded([&] { *out =
 int capital_cholinv_get(void* p, int which, double* host) { return guarded([&] { ((cholinv_problem*)p)->get(which, host); }); }
 int capital_cholinv_dims(void* p, int64_t* nloc, int* x, int* y, int* z, int* d, int* c) { return guarded([&] { ((cholinv_problem*)p)->dims(nloc, x, y, z, d, c); }); }
 int capital_cholinv_stats(void* p, int64_t* bc, int64_t* levels, int64_t* bcdim) { return guarded([&] { ((cholinv_problem*)p)->stats(bc, levels, bcdim); }); }
-// TRSM mode (info::solve_with_trsm): potrf + block TRSM + SYRK recursion, no inverse formed; one GPU per matrix
+// TRSM mode (info::solve_with_trsm): potrf + block TRSM + SYRK recursion, no inverse formed (one GPU, or a d x d x c grid: potrf_rec_grid)
 int capital_cholinv_set_trsm_mode(void* p, int on) { return guarded([&] { ((cholinv_problem*)p)->set_trsm_mode(on != 0); }); }
 int capital_cholinv_destroy(void* p) { return guarded([&] { capital::sync(); delete (cholinv_problem*)p; }); }
 

@@ -56,7 +56,7 @@ public:
     // TRSM mode (not in the reference, which has no TRSM anywhere; BASELINE north_star names the kernel): factor() runs the
     // textbook right-looking recursion -- potrf on the diagonal block, R12 = R11^-T A12 by a block TRSM, trailing SYRK -- and
     // forms NO inverse: n^3/3 executed flops instead of 5 n^3/12.  R is the same factor; Rinv is not formed (construct_Rinv
-    // throws).  One GPU per matrix (d == 1).  Default off: the reference-exact schedule.
+    // throws).  One GPU, or a d x d x c grid (potrf_rec_grid).  Default off: the reference-exact schedule.
     bool solve_with_trsm = false;
     // LAPACK info of the factorisation (the reference drops it, lapack/interface.hpp:39,54): 0, or the 1-based position,
     // inside the first diagonal block that failed, of the first non-positive pivot.  factor() throws std::domain_error then.
@@ -200,7 +200,6 @@ public:
   template <typename MatrixType, typename ArgType, typename CommType>
   static void factor_trsm(const MatrixType& A, ArgType& args, CommType&& CommInfo) {
     using U = typename ArgType::DimensionType;
-    if (CommInfo.d != 1) throw std::invalid_argument("cholinv: the TRSM mode keeps the matrix on one GPU (d == 1); grids use the reference schedule");
     capi_handle_t h = capital::handle();
     const U ld = A.num_rows_local();
     CAPITAL_CHECK(capi_stream_select(h, 0));
@@ -219,11 +218,104 @@ public:
     args.globalDimension = args.trueGlobalDimension = A.num_rows_global();
     args.bcDimension = (U)CommInfo.d * bcDimLocal;
     args.num_base_cases = args.num_levels = 0;
-    potrf_rec(args, R, ld, (U)0, ld);
+    if (CommInfo.d == 1) {
+      potrf_rec(args, R, ld, (U)0, ld);                 // (d == 1, c > 1: every layer holds the whole matrix and factors it)
+    } else {
+      // d x d x c grid (round 3): the arena holds, at the top level, the assembled R11 and R12 (4 h^2 each), the gathered pieces behind
+      // them (4 h^2 each) and what the trailing update's SUMMA needs
+      const U hh = ld - (ld >> args.split);
+      args.work.reserve((int64_t)32 * hh * hh + 4 * (int64_t)args.bcDimension * args.bcDimension + 4096);
+      potrf_rec_grid(args, CommInfo, R, ld, (U)0, ld);
+    }
     if (packed) serialize<uppertri, uppertri>::invoke(args.Rfull, args.R, 0, ld, 0, ld, 0, ld, 0, ld);
     CAPITAL_CHECK(capi_get_info(h, &args.potrf_info));
-    if (args.potrf_info != 0)
+    const int failed = capital::ranks_with_nonzero(CommInfo.world, args.potrf_info);       // (replicated base cases: all ranks see it; agreed on anyway)
+    if (failed != 0)
       throw std::domain_error("cholinv::factor (TRSM mode): the matrix is not positive definite (non-positive pivot " + std::to_string(args.potrf_info) + " of a diagonal block)");
+  }
+
+  // TRSM mode on a d x d x c grid (d > 1).  The element-cyclic layout has block size ONE, so a triangular solve cannot be pipelined over
+  // block rows the way ScaLAPACK does it; instead the solve is made LOCAL:
+  //   2'. every rank assembles R11 (all-gather of the d^2 pieces over `slice`, re-indexed cyclic -> global: the base case's machinery at
+  //       the order of a recursion level) and the whole A12; the P = d^2 c ranks of the grid each solve S2 / P global COLUMNS of
+  //       R11^T X = A12 with the block TRSM (capi_dtrsm: no flop is done twice), the solved column ranges are all-gathered IN PLACE over
+  //       the world communicator (they are contiguous column blocks of the global image), and every rank keeps its own cyclic piece;
+  //   3.  A22 -= R12^T R12 by the triangular-output SUMMA of the reference schedule (partner exchange, row / column broadcasts, depth sum).
+  // Base case: the aggregate is gathered and factored on every rank (ReplicateCommComp's pattern, policy.h:160-224, without the inverse).
+  // Bytes per rank and level: ~7 h^2 for step 2' against 3 h^2 for the reference's TRMM SUMMA -- this mode trades communication for
+  // arithmetic (n^3/3 executed, no inverse); on one node's mesh with multi-path transfers for the update it is the cheaper of the two
+  // only when the links are not the limit.  Parity: R is unique, so the assembled factor must equal the one-GPU factor (tests).
+  template <typename ArgType, typename CommType, typename U>
+  static void potrf_rec_grid(ArgType& args, CommType&& t, double* R, U ld, U start, U dim) {
+    using matmult::view;
+    capi_handle_t h = capital::handle();
+    matmult::arena& ws = args.work;
+    const int64_t d = (int64_t)t.d, P = (int64_t)t.size, me = (int64_t)t.x + d * (int64_t)t.y;
+    const U split1 = dim >> args.split;
+    double* R11 = R + start + start * ld;
+    if (((dim * (U)t.d) <= args.bcDimension) || (split1 < args.split)) {                              // cholinv.hpp:93
+      CRITTER_START(CI::factor_diag);
+      const int64_t L = dim, agg = L * d;
+      const int64_t span = ((start + dim) != args.trueLocalDimension) ? agg : agg - (args.trueLocalDimension * d - args.trueGlobalDimension);
+      const int64_t mark = ws.top;
+      double* mine = ws.take(L * L);
+      double* blocked = ws.take(L * L * d * d);
+      double* cyc = ws.take(agg * agg);
+      CAPITAL_CHECK(capi_dlacpy(h, 0, L, L, R11, ld, mine, L));
+      CAPITAL_CHECK(capi_allgather(t.slice, mine, blocked, L * L));
+      util::block_to_cyclic_rect(blocked, cyc, L, L, d);
+      CAPITAL_CHECK(capi_dpotrf(h, CAPI_UPPER, span, cyc, agg));
+      CAPITAL_CHECK(capi_dtrizero(h, CAPI_UPPER, agg, cyc, agg));
+      util::cyclic_to_block_rect(blocked, cyc, L, L, d);
+      CAPITAL_CHECK(capi_dlacpy(h, 0, L, L, blocked + me * L * L, L, R11, ld));
+      ws.top = mark;
+      ++args.num_base_cases;
+      CRITTER_STOP(CI::factor_diag);
+      return;
+    }
+    ++args.num_levels;
+    const U split2 = dim - split1;
+    double* R12 = R + start + (start + split1) * ld;
+    view A22{R + (start + split1) + (start + split1) * ld, ld, split2, split2};
+    potrf_rec_grid(args, t, R, ld, start, split1);
+    CRITTER_START(CI::trsm);
+    const int64_t mark = ws.top;
+    view W{ws.take((int64_t)split1 * split2), split1, split1, split2};                                 // this rank's piece of R12, contiguous
+    {
+      const int64_t L1 = split1, L2 = split2, S1 = L1 * d, S2 = L2 * d;
+      const int64_t ncw = (((S2 + P - 1) / P) + 1) & ~(int64_t)1, S2p = ncw * P;                       // columns per rank (even), padded width
+      const int64_t inner = ws.top;
+      double* Rf = ws.take(S1 * S1);
+      double* Xf = ws.take(S1 * S2p);
+      double* mine = ws.take(L1 * std::max(L1, L2));
+      double* blocked = ws.take(L1 * std::max(L1, L2) * d * d);
+      CAPITAL_CHECK(capi_dlacpy(h, 0, L1, L1, R11, ld, mine, L1));
+      CAPITAL_CHECK(capi_allgather(t.slice, mine, blocked, L1 * L1));
+      util::block_to_cyclic_rect(blocked, Rf, L1, L1, d);                                             // (zeroes the strictly lower part)
+      CAPITAL_CHECK(capi_dlacpy(h, 0, L1, L2, R12, ld, mine, L1));
+      CAPITAL_CHECK(capi_allgather(t.slice, mine, blocked, L1 * L2));
+      if (S2p > S2) capital::dev_zero(Xf + S1 * S2, S1 * (S2p - S2));
+      CAPITAL_CHECK(capi_block_to_cyclic_full(h, blocked, Xf, L1, L2, d));
+      // this rank's columns: [rank ncw, (rank + 1) ncw) of the global block -- every layer holds the same image, so the P ranks share the work
+      double* Xw = Xf + (int64_t)t.rank * ncw * S1;
+      CAPITAL_CHECK(capi_dtrsm(h, CAPI_LEFT, CAPI_UPPER, CAPI_TRANS, CAPI_NONUNIT, S1, ncw, 1.0, Rf, S1, Xw, S1));
+      CAPITAL_CHECK(capi_allgather(t.world, Xw, Xf, S1 * ncw));                                        // in place: send = recv + rank * count
+      CAPITAL_CHECK(capi_cyclic_to_block(h, blocked, Xf, L1, L2, d));
+      CAPITAL_CHECK(capi_dlacpy(h, 0, L1, L2, blocked + me * L1 * L2, L1, W.p, W.ld));
+      CAPITAL_CHECK(capi_dlacpy(h, 0, L1, L2, W.p, W.ld, R12, ld));
+      ws.top = inner;
+    }
+    CRITTER_STOP(CI::trsm);
+    CRITTER_START(CI::tmu);
+    {
+      view Wx{ws.take(W.count()), split1, split1, split2};
+      capital::dev_copy(Wx.p, W.p, W.count());
+      util::transpose_raw(Wx.p, Wx.count(), ws.take(Wx.count()), t, matmult::summa::relay_space(t, Wx.count(), ws));
+      matmult::summa::syrk(t, CAPI_UPPER, CAPI_TRANS, -1.0, W, Wx, 1.0, A22, ws);
+    }
+    ws.top = mark;
+    CRITTER_STOP(CI::tmu);
+    potrf_rec_grid(args, t, R, ld, start + split1, split2);
   }
 
   template <typename ArgType, typename U>

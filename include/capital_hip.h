@@ -142,6 +142,8 @@ int capi_remove_triangle(capi_handle_t h, char dir, double* A, int64_t dimX, int
  * are d*d local blocks of rows_local x cols_local; cyclic is the (rows_local*d) x (cols_local*d) aggregate */
 int capi_block_to_cyclic(capi_handle_t h, const double* blocked, double* cyclic, int64_t rows_local, int64_t cols_local, int64_t d);
 int capi_cyclic_to_block(capi_handle_t h, double* blocked, const double* cyclic, int64_t rows_local, int64_t cols_local, int64_t d);
+/* the same assembly for an OFF-diagonal aggregate (the R12 block a grid solves in TRSM mode): no part of it is zeroed */
+int capi_block_to_cyclic_full(capi_handle_t h, const double* blocked, double* cyclic, int64_t rows_local, int64_t cols_local, int64_t d);
 /* the same for PACKED upper-triangular pieces of rows_local (rows_local + 1) / 2 doubles each (util::block_to_cyclic_triangle /
  * cyclic_to_block_triangle, util.hpp:57-102,167-201: the Serialize policy's base-case messages, policy.h:176,322-377) */
 int capi_block_to_cyclic_tri(capi_handle_t h, const double* blocked_packed, double* cyclic, int64_t rows_local, int64_t d);

@@ -30,12 +30,13 @@ def main():
         os.environ.update(case.get("env", {}))
         if case["kind"] == "cholinv":
             p = driver.Cholinv(case["n"], c=case["c"], complete_inv=case["ci"], split=1, bc_mult=case["bc"], layout=case.get("layout", 0),
-                               num_chunks=case.get("chunks", 0), serialize=case["serialize"], bc_policy=case["policy"])
+                               num_chunks=case.get("chunks", 0), serialize=case["serialize"], bc_policy=case["policy"], trsm_mode=case.get("trsm", False))
             p.generate()
             p.factor()
             p.factor()                      # a second call reuses communicators, streams, events and workspaces
             res = p.residual()
-            np.savez(os.path.join(cfg["dir"], f"{tag}_rank{rank}.npz"), R=p.R(), Rinv=p.Rinv(), xyz=np.array([p.x, p.y, p.z, p.d, p.c]),
+            Rinv = p.Rinv() if not case.get("trsm", False) else np.zeros((1, 1))     # TRSM mode forms no inverse
+            np.savez(os.path.join(cfg["dir"], f"{tag}_rank{rank}.npz"), R=p.R(), Rinv=Rinv, xyz=np.array([p.x, p.y, p.z, p.d, p.c]),
                      residual=res, stats=np.array(list(p.stats().values())))
             p.close()
         else:

@@ -191,6 +191,14 @@ int capi_cyclic_to_block(capi_handle_t, double* blocked, const double* cyclic, i
   orc_cyclic_to_block_rect(blocked, cyclic, rl, cl, d);
   return 0;
 }
+int capi_block_to_cyclic_full(capi_handle_t, const double* blocked, double* cyclic, int64_t rl, int64_t cl, int64_t d) {
+  const int64_t rg = rl * d;                                   // piece (x, y) = slice rank x + d y holds global (column i d + x, row k d + y)
+  for (int64_t y = 0; y < d; ++y)
+    for (int64_t x = 0; x < d; ++x)
+      for (int64_t i = 0; i < cl; ++i)
+        for (int64_t k = 0; k < rl; ++k) cyclic[(i * d + x) * rg + (k * d + y)] = blocked[(y * d + x) * rl * cl + i * rl + k];
+  return 0;
+}
 int capi_block_to_cyclic_tri(capi_handle_t, const double* blocked, double* cyclic, int64_t rl, int64_t d) {
   orc_block_to_cyclic_triangle(blocked, cyclic, d * d * (rl * (rl + 1) / 2), rl, rl, d);
   return 0;

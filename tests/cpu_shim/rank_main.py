@@ -124,7 +124,8 @@ def main():
     out = {"rank": rank}
     if cfg["kind"] == "cholinv":
         p = driver.Cholinv(cfg["n"], c=cfg["c"], complete_inv=cfg["ci"], split=cfg.get("split", 1), bc_mult=cfg["bc"],
-                           layout=cfg.get("layout", 0), num_chunks=cfg.get("chunks", 0), serialize=cfg["serialize"], bc_policy=cfg["policy"])
+                           layout=cfg.get("layout", 0), num_chunks=cfg.get("chunks", 0), serialize=cfg["serialize"], bc_policy=cfg["policy"],
+                           trsm_mode=cfg.get("trsm", False))
         p.generate()
         if "spoil" in cfg:
             # a non-SPD input: global diagonal element g made negative on the rank that owns it (local (i,j) <-> global (x + i d, y + j d))
@@ -148,7 +149,8 @@ def main():
             return
         p.factor()
         res = p.residual()
-        np.savez(os.path.join(cfg["dir"], f"rank{rank}.npz"), A=p.A(), R=p.R(), Rinv=p.Rinv(), xyz=np.array([p.x, p.y, p.z, p.d, p.c]),
+        Rinv = p.Rinv() if not cfg.get("trsm", False) else np.zeros((1, 1))      # TRSM mode forms no inverse
+        np.savez(os.path.join(cfg["dir"], f"rank{rank}.npz"), A=p.A(), R=p.R(), Rinv=Rinv, xyz=np.array([p.x, p.y, p.z, p.d, p.c]),
                  residual=res, stats=np.array(list(p.stats().values())))
         p.close()
     else:

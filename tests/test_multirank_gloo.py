@@ -103,6 +103,34 @@ def test_cholinv_on_grids(oracle, shim_lib, world, c, n, bc, ci, serialize, poli
         assert len(levels) == 1            # every rank walked the same recursion
 
 
+@pytest.mark.parametrize("world,c,n,bc,serialize,chunks", [(8, 2, 192, -2, True, 0), (8, 2, 200, -1, False, 3), (4, 1, 128, -2, True, 0),
+                                                           (4, 1, 97, -2, False, 0), (2, 2, 128, -2, True, 0)])
+def test_cholinv_trsm_mode_on_grids(oracle, shim_lib, world, c, n, bc, serialize, chunks):
+    """TRSM mode (info::solve_with_trsm: POTRF + block TRSM + SYRK, no inverse) on d x d x c grids (cholinv.h: potrf_rec_grid): R11 and
+    the A12 block are assembled on every rank, each rank solves its share of global columns with the block TRSM, the solved ranges are
+    all-gathered in place, the trailing update is the reference schedule's SUMMA.  R must equal the 1-rank oracle's factor."""
+    with tempfile.TemporaryDirectory() as d:
+        _launch(world, {"kind": "cholinv", "n": n, "c": c, "bc": bc, "ci": 0, "serialize": serialize, "policy": 0, "chunks": chunks, "trsm": True,
+                        "dir": d})
+        A = oracle.distribute_symmetric(n, n, 0, 0, 1, 1)
+        Rg = np.zeros((n, n), order="F")
+        reps = {}
+        for r in range(world):
+            z = np.load(os.path.join(d, f"rank{r}.npz"))
+            x, y, zz, dd, cc = [int(v) for v in z["xyz"]]
+            assert float(z["residual"]) <= 1e-14
+            reps.setdefault((x, y), []).append(z["R"])
+            if zz == 0:
+                oracle.cyclic_insert(Rg, np.asfortranarray(z["R"]), x, y, dd, dd)
+        for blocks in reps.values():
+            for other in blocks[1:]:
+                np.testing.assert_array_equal(other, blocks[0])           # depth replicas agree bit for bit
+        Rref, _, info = oracle.cholinv_factor(A, 0, 1, bc, c, dd)
+        assert info == 0
+        assert np.abs(Rg - Rref).max() <= 1e-12 * np.abs(Rref).max()
+        assert np.count_nonzero(np.tril(Rg, -1)) == 0
+
+
 @pytest.mark.parametrize("world,c,policy,serialize", [(8, 2, 0, True), (8, 2, 1, False), (8, 2, 2, True), (8, 2, 3, False), (4, 1, 2, False), (2, 2, 1, True)])
 def test_non_spd_input_unwinds_every_rank(shim_lib, world, c, policy, serialize):
     """Only the ranks that factor the aggregate see LAPACK's info (layer 0 with ReplicateComp, the slice root with NoReplication[Overlap],

@@ -95,9 +95,11 @@ def recorded_traffic(n, gpus):
     a RECORDED figure (`traffic_source` names the files), or None when no pass of this configuration is committed."""
     import csv
     # (file pattern, trailing rows that belong to the residual check's products rather than to factor())
-    tag, drop = {(65536, 1): ("r2_pmc_{}_bench_n65536.csv", 0), (32768, 1): ("r1_d_pmc_{}_bench_step.csv", 1)}.get((n, gpus), (None, 0))
+    tag, drop = {(65536, 1): ("r3_pmc_{}_bench_n65536.csv", 0), (32768, 1): ("r1_d_pmc_{}_bench_step.csv", 1)}.get((n, gpus), (None, 0))
     if tag is None:
         return None, None
+    if not os.path.exists(os.path.join(ROOT, "profiles", tag.format("fe"))):
+        tag = tag.replace("r3_", "r2_")              # (the previous round's capture until this round's is committed)
     tot, launches = 0.0, 0
     try:
         for t, name in (("fe", "FETCH_SIZE"), ("wr", "WRITE_SIZE")):
@@ -109,7 +111,13 @@ def recorded_traffic(n, gpus):
         return None, None
     if not launches:
         return None, None
-    return tot / launches, f"recorded: profiles/{tag.format('{fe,wr}')}: 2 x FETCH_SIZE + WRITE_SIZE, mean of the {launches} launches of one factor()"
+    commit = ""
+    try:
+        commit = open(os.path.join(ROOT, "profiles", tag[:2] + "_capture_commit.txt")).read().split()[0]
+    except (OSError, IndexError):
+        pass
+    return tot / launches, (f"recorded: profiles/{tag.format('{fe,wr}')}: 2 x FETCH_SIZE + WRITE_SIZE, mean of the {launches} launches of one factor()"
+                            + (f"; captured at commit {commit}" if commit else ""))
 
 
 def time_cholesky(driver, L, h, n, c, bc, chunks, steps, warmup, distributed, device, bc_policy, trsm_mode=False, multipath=None):

@@ -115,7 +115,7 @@ public:
     const int64_t mark = ws.top;
     view acc = t.c > 1 ? view{ws.take(M * N), M, M, N} : C;
     const size_t steps = t.d > 1 ? t.d / t.c : 1;
-    const bool piped = t.num_chunks > 0 && steps == 1 && transB == CAPI_NOTRANS && (t.d > 1 || t.c > 1);
+    const bool piped = t.num_chunks > 0 && transB == CAPI_NOTRANS && (t.d > 1 || t.c > 1);
     const int nch = piped ? chunk_count(t.num_chunks, N) : 1;
     pipe P(piped && nch > 1);
     enum { E0 = 0, EA = 1, EB = 2, EC = 70, ER = 140 };
@@ -141,42 +141,48 @@ public:
       ws.top = mark;
       return;
     }
-    // ---- pipelined over the output's column chunks
+    // ---- pipelined over the output's column chunks; every K-class step s of this layer contributes to every chunk
     const bool sliced = (t.d == 1);
     int64_t k0 = 0, k1 = K;
-    view a = A, b = B;
-    const size_t q = t.z;
-    const bool rootB = sliced || (t.y == q);
+    std::vector<view> a(steps, A), b(steps, B);
     P.main(); P.rec(E0);
     P.comm(); P.wait(E0);
     if (sliced) {
       kslice(K, t.c, t.z, k0, k1);
     } else {
-      a = panel(t, AX_ROW, 0, A, ws);
-      b = view{(rootB && B.contiguous()) ? B.p : ws.take(B.count()), B.rows, B.rows, B.cols};
+      for (size_t s = 0; s < steps; ++s) {
+        a[s] = panel(t, AX_ROW, s, A, ws);
+        const bool rootB = t.y == t.z + s * t.c;
+        b[s] = view{(rootB && B.contiguous()) ? B.p : ws.take(B.count()), B.rows, B.rows, B.cols};
+      }
     }
     P.rec(EA);
     int64_t cmax = 0;
     for (int j = 0; j < nch; ++j) { int64_t c0, c1; chunk_range(N, nch, j, c0, c1); cmax = std::max(cmax, c1 - c0); }
-    double* relay = relay_space(t, std::max(b.rows, acc.rows) * cmax, ws);
+    double* relay = relay_space(t, std::max(B.rows, acc.rows) * cmax, ws);
     for (int j = 0; j < nch; ++j) {
       int64_t c0, c1;
       chunk_range(N, nch, j, c0, c1);
-      if (!sliced && c1 > c0) {
-        if (rootB && !B.contiguous()) CAPITAL_CHECK(capi_dlacpy(h, 0, B.rows, c1 - c0, B.p + c0 * B.ld, B.ld, b.p + c0 * b.ld, b.ld));
-        bcast_axis(t, AX_COLUMN, 0, b.p + c0 * b.ld, b.rows * (c1 - c0), relay);
-      }
+      if (!sliced && c1 > c0)
+        for (size_t s = 0; s < steps; ++s) {
+          const bool rootB = t.y == t.z + s * t.c;
+          if (rootB && !B.contiguous()) CAPITAL_CHECK(capi_dlacpy(h, 0, B.rows, c1 - c0, B.p + c0 * B.ld, B.ld, b[s].p + c0 * b[s].ld, b[s].ld));
+          bcast_axis(t, AX_COLUMN, s, b[s].p + c0 * b[s].ld, b[s].rows * (c1 - c0), relay);
+        }
       P.rec(EB + j);
     }
     P.main(); P.wait(EA);
-    const double bt = t.c > 1 ? 0.0 : beta;
-    const double* ap = sliced ? (transA ? a.p + k0 : a.p + k0 * a.ld) : a.p;
     for (int j = 0; j < nch; ++j) {
       int64_t c0, c1;
       chunk_range(N, nch, j, c0, c1);
       P.wait(EB + j);
       if (c1 > c0)
-        CAPITAL_CHECK(capi_dgemm(h, transA, CAPI_NOTRANS, M, c1 - c0, k1 - k0, alpha, ap, a.ld, b.p + k0 + c0 * b.ld, b.ld, bt, acc.p + c0 * acc.ld, acc.ld));
+        for (size_t s = 0; s < steps; ++s) {
+          const double bt = s ? 1.0 : (t.c > 1 ? 0.0 : beta);
+          const double* ap = sliced ? (transA ? a[s].p + k0 : a[s].p + k0 * a[s].ld) : a[s].p;
+          CAPITAL_CHECK(capi_dgemm(h, transA, CAPI_NOTRANS, M, c1 - c0, k1 - k0, alpha, ap, a[s].ld, b[s].p + k0 + c0 * b[s].ld, b[s].ld, bt,
+                                   acc.p + c0 * acc.ld, acc.ld));
+        }
       P.rec(EC + j);
     }
     if (t.c > 1) {
@@ -245,7 +251,7 @@ public:
     // chunk j of the output needs B's column chunks 0..j, which arrive in that order.
     const bool piped_left = side == CAPI_LEFT;
     const bool piped_right = side == CAPI_RIGHT && eff_upper && trans == CAPI_NOTRANS && t.d > 1;
-    const bool piped = t.num_chunks > 0 && (piped_left || piped_right) && steps == 1 && Cout.contiguous();
+    const bool piped = t.num_chunks > 0 && (piped_left || piped_right) && Cout.contiguous();
     const int nch = piped ? chunk_count(t.num_chunks, N) : 1;
     pipe P(piped && nch > 1);
     enum { E0 = 0, ET = 1, EB = 2, EC = 70, ER = 140 };
@@ -299,24 +305,28 @@ public:
         CAPITAL_CHECK(capi_dtrmm_acc(h, side, uplo, trans, diag, M, N, alpha, tt.p, tt.ld, bb.p, bb.ld, s ? 1.0 : 0.0, Cout.p, Cout.ld));
       }
     } else {
-      // one K-class (q = z): T first (whole, packed), then B column chunk by column chunk on the communication stream
-      const size_t q = t.z;
-      const int axB = side == CAPI_LEFT ? AX_COLUMN : AX_ROW;
-      const bool rootB = (side == CAPI_LEFT ? t.y : t.x) == q;
+      // every K-class step of this layer: the T panels first (whole, packed), then the B panels column chunk by column chunk on the
+      // communication stream; chunk j of the output sums the steps' products
+      const int axT = side == CAPI_LEFT ? AX_ROW : AX_COLUMN, axB = side == CAPI_LEFT ? AX_COLUMN : AX_ROW;
       P.main(); P.rec(E0);
       P.comm(); P.wait(E0);
-      view tt = panel_tri(t, side == CAPI_LEFT ? AX_ROW : AX_COLUMN, 0, T, uplo, ws);
+      std::vector<view> tt(steps, T), bb(steps, view{nullptr, B.rows, B.rows, B.cols});
+      for (size_t s = 0; s < steps; ++s) tt[s] = panel_tri(t, axT, s, T, uplo, ws);
       P.rec(ET);
-      view bb{nullptr, B.rows, B.rows, B.cols};
-      bb.p = (rootB && B.contiguous()) ? B.p : ws.take(B.count());
+      for (size_t s = 0; s < steps; ++s) {
+        const bool rootB = (side == CAPI_LEFT ? t.y : t.x) == t.z + s * t.c;
+        bb[s].p = (rootB && B.contiguous()) ? B.p : ws.take(B.count());
+      }
       double* relay = relay_space(t, B.rows * cmax, ws);
       for (int j = 0; j < nch; ++j) {
         int64_t c0, c1;
         chunk_range(N, nch, j, c0, c1);
-        if (c1 > c0) {
-          if (rootB && !B.contiguous()) CAPITAL_CHECK(capi_dlacpy(h, 0, B.rows, c1 - c0, B.p + c0 * B.ld, B.ld, bb.p + c0 * bb.ld, bb.ld));
-          bcast_axis(t, axB, 0, bb.p + c0 * bb.ld, bb.rows * (c1 - c0), relay);
-        }
+        if (c1 > c0)
+          for (size_t s = 0; s < steps; ++s) {
+            const bool rootB = (side == CAPI_LEFT ? t.y : t.x) == t.z + s * t.c;
+            if (rootB && !B.contiguous()) CAPITAL_CHECK(capi_dlacpy(h, 0, B.rows, c1 - c0, B.p + c0 * B.ld, B.ld, bb[s].p + c0 * bb[s].ld, bb[s].ld));
+            bcast_axis(t, axB, s, bb[s].p + c0 * bb[s].ld, bb[s].rows * (c1 - c0), relay);
+          }
         P.rec(EB + j);
       }
       P.main(); P.wait(ET);
@@ -326,14 +336,17 @@ public:
         P.wait(EB + j);
         if (c1 > c0) {
           double* Cj = Cout.p + c0 * Cout.ld;
-          if (side == CAPI_LEFT) {
-            CAPITAL_CHECK(capi_dtrmm_oop(h, side, uplo, trans, diag, M, c1 - c0, alpha, tt.p, tt.ld, bb.p + c0 * bb.ld, bb.ld, Cj, Cout.ld));
-          } else {
-            // Cout[:, chunk] = alpha ( B[:, 0:c0] T[0:c0, chunk] + B[:, chunk] T[chunk, chunk] ): a rectangle above the chunk's triangle
-            if (c0 > 0)
-              CAPITAL_CHECK(capi_dgemm(h, CAPI_NOTRANS, CAPI_NOTRANS, M, c1 - c0, c0, alpha, bb.p, bb.ld, tt.p + c0 * tt.ld, tt.ld, 0.0, Cj, Cout.ld));
-            CAPITAL_CHECK(capi_dtrmm_acc(h, side, uplo, trans, diag, M, c1 - c0, alpha, tt.p + c0 + c0 * tt.ld, tt.ld, bb.p + c0 * bb.ld, bb.ld,
-                                         c0 > 0 ? 1.0 : 0.0, Cj, Cout.ld));
+          for (size_t s = 0; s < steps; ++s) {
+            const double b0 = s ? 1.0 : 0.0;
+            if (side == CAPI_LEFT) {
+              CAPITAL_CHECK(capi_dtrmm_acc(h, side, uplo, trans, diag, M, c1 - c0, alpha, tt[s].p, tt[s].ld, bb[s].p + c0 * bb[s].ld, bb[s].ld, b0, Cj, Cout.ld));
+            } else {
+              // Cout[:, chunk] += alpha ( B[:, 0:c0] T[0:c0, chunk] + B[:, chunk] T[chunk, chunk] ): a rectangle above the chunk's triangle
+              if (c0 > 0)
+                CAPITAL_CHECK(capi_dgemm(h, CAPI_NOTRANS, CAPI_NOTRANS, M, c1 - c0, c0, alpha, bb[s].p, bb[s].ld, tt[s].p + c0 * tt[s].ld, tt[s].ld, b0, Cj, Cout.ld));
+              CAPITAL_CHECK(capi_dtrmm_acc(h, side, uplo, trans, diag, M, c1 - c0, alpha, tt[s].p + c0 + c0 * tt[s].ld, tt[s].ld, bb[s].p + c0 * bb[s].ld, bb[s].ld,
+                                           (c0 > 0 || s) ? 1.0 : 0.0, Cj, Cout.ld));
+            }
           }
         }
         P.rec(EC + j);
@@ -377,7 +390,7 @@ public:
     const int64_t mark = ws.top;
     const size_t steps = t.d > 1 ? t.d / t.c : 1;
     // the pipeline is built for what cholinv issues: upper triangle, transposed form, one K-class per layer
-    const bool piped = t.num_chunks > 0 && trans && uplo == CAPI_UPPER && steps == 1;
+    const bool piped = t.num_chunks > 0 && trans && uplo == CAPI_UPPER;
     const int nch = piped ? chunk_count(t.num_chunks, N) : 1;
     pipe P(piped && nch > 1);
     enum { E0 = 0, EL = 1, EB = 2, EC = 70, ER = 140 };
@@ -408,12 +421,10 @@ public:
       ws.top = mark;
       return;
     }
-    // ---- pipelined: C(upper)[:, chunk] = alpha * L[:, 0:c1]^T * R[:, chunk]; L and R are K x N, k-contiguous
+    // ---- pipelined: C(upper)[:, chunk] = alpha * sum over this layer's K-class steps of L_s[:, 0:c1]^T * R_s[:, chunk]; K x N, k-contiguous
     int64_t k0 = 0, k1 = K;
-    view l = Bx, r = A;
+    std::vector<view> l(steps, Bx), r(steps, A);
     const bool sliced = (t.d == 1);
-    const size_t q = t.z;
-    const bool rootR = sliced || (t.y == q);
     int64_t cmax = 0;
     for (int j = 0; j < nch; ++j) { int64_t c0, c1; chunk_range(N, nch, j, c0, c1); cmax = std::max(cmax, c1 - c0); }
     P.main(); P.rec(E0);
@@ -421,34 +432,40 @@ public:
     if (sliced) {
       kslice(K, t.c, t.z, k0, k1);
     } else {
-      l = panel(t, AX_ROW, 0, Bx, ws);
-      r = view{(rootR && A.contiguous()) ? A.p : ws.take(A.count()), A.rows, A.rows, A.cols};
+      for (size_t s = 0; s < steps; ++s) {
+        l[s] = panel(t, AX_ROW, s, Bx, ws);
+        const bool rootR = t.y == t.z + s * t.c;
+        r[s] = view{(rootR && A.contiguous()) ? A.p : ws.take(A.count()), A.rows, A.rows, A.cols};
+      }
     }
     P.rec(EL);
     double* relay = relay_space(t, std::max(A.rows, N) * cmax, ws);
     for (int j = 0; j < nch; ++j) {
       int64_t c0, c1;
       chunk_range(N, nch, j, c0, c1);
-      if (!sliced && c1 > c0) {
-        if (rootR && !A.contiguous()) CAPITAL_CHECK(capi_dlacpy(h, 0, A.rows, c1 - c0, A.p + c0 * A.ld, A.ld, r.p + c0 * r.ld, r.ld));
-        bcast_axis(t, AX_COLUMN, 0, r.p + c0 * r.ld, r.rows * (c1 - c0), relay);
-      }
+      if (!sliced && c1 > c0)
+        for (size_t s = 0; s < steps; ++s) {
+          const bool rootR = t.y == t.z + s * t.c;
+          if (rootR && !A.contiguous()) CAPITAL_CHECK(capi_dlacpy(h, 0, A.rows, c1 - c0, A.p + c0 * A.ld, A.ld, r[s].p + c0 * r[s].ld, r[s].ld));
+          bcast_axis(t, AX_COLUMN, s, r[s].p + c0 * r[s].ld, r[s].rows * (c1 - c0), relay);
+        }
       P.rec(EB + j);
     }
     P.main(); P.wait(EL);
-    if (t.c > 1) capital::dev_zero(acc.p, acc.count());       // whole columns are summed over depth below
-    const double bt = t.c > 1 ? 0.0 : beta;
+    if (t.c > 1) capital::dev_zero(acc.p, acc.count());       // (the part below the computed trapezoids is folded into C as zeros)
     for (int j = 0; j < nch; ++j) {
       int64_t c0, c1;
       chunk_range(N, nch, j, c0, c1);
       P.wait(EB + j);
-      if (c1 > c0) {
-        const double* rj = r.p + k0 + c0 * r.ld;
-        if (c0 > 0)   // rows above the diagonal block of this chunk: a plain rectangle
-          CAPITAL_CHECK(capi_dgemm(h, CAPI_TRANS, CAPI_NOTRANS, c0, c1 - c0, k1 - k0, alpha, l.p + k0, l.ld, rj, r.ld, bt, acc.p + c0 * acc.ld, acc.ld));
-        CAPITAL_CHECK(capi_dgemmt(h, CAPI_UPPER, CAPI_TRANS, CAPI_NOTRANS, c1 - c0, k1 - k0, alpha, l.p + k0 + c0 * l.ld, l.ld, rj, r.ld, bt,
-                                  acc.p + c0 + c0 * acc.ld, acc.ld));
-      }
+      if (c1 > c0)
+        for (size_t s = 0; s < steps; ++s) {
+          const double bt = s ? 1.0 : (t.c > 1 ? 0.0 : beta);
+          const double* rj = r[s].p + k0 + c0 * r[s].ld;
+          if (c0 > 0)   // rows above the diagonal block of this chunk: a plain rectangle
+            CAPITAL_CHECK(capi_dgemm(h, CAPI_TRANS, CAPI_NOTRANS, c0, c1 - c0, k1 - k0, alpha, l[s].p + k0, l[s].ld, rj, r[s].ld, bt, acc.p + c0 * acc.ld, acc.ld));
+          CAPITAL_CHECK(capi_dgemmt(h, CAPI_UPPER, CAPI_TRANS, CAPI_NOTRANS, c1 - c0, k1 - k0, alpha, l[s].p + k0 + c0 * l[s].ld, l[s].ld, rj, r[s].ld, bt,
+                                    acc.p + c0 + c0 * acc.ld, acc.ld));
+        }
       P.rec(EC + j);
     }
     if (t.c > 1) {

@@ -60,7 +60,8 @@ def _launch(world, cfg, timeout=600, multipath=True):
     (2, 2, 160, -2, 1, False, (0, 3)),   # (policy, num_chunks): chunked / overlapped SUMMA pipeline, K-sliced grid
     (8, 2, 192, -2, 1, True, (0, 3)),    # same on the cubic grid
     (8, 2, 200, -1, 0, False, (2, 5)),
-    (4, 1, 128, -1, 1, False, (0, 4)),   # two K-classes per layer: pipeline must stay off, results unchanged
+    (4, 1, 128, -1, 1, False, (0, 4)),   # two K-class steps per layer: every chunk sums both steps' products
+    (4, 1, 131, -2, 1, True, (2, 3)),    # ... with a padded order and packed pieces
     (2, 2, 128, -1, 0, True, 2),
     (4, 1, 128, -1, 1, False, 0),
     (4, 1, 97, -2, 0, True, 1),        # grid does not divide n: padding path

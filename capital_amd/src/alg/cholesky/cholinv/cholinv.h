@@ -153,7 +153,8 @@ public:
     // (single GPU: the R12 copies of nested levels stay live while their trailing updates run beside the recursion: h^2 (1 + 1/4 + ...))
     // (grids: the update's W, its exchanged copy + staging, two panels, the partial sums + their packed image, relay space and the landing
     //  half of the multi-path pair transfers, per-chunk copies of a pipelined multiply)
-    int64_t need = single ? (int64_t)h * h + (int64_t)h * h / 3 + 1024 : (int64_t)12 * h * h + 4 * (int64_t)agg * agg + 4096;
+    //  (the K-sliced grids, d == 1, broadcast and relay nothing: 8 h^2 as in round 2 -- at n = 65536 on 1 x 1 x 2 h^2 is 8 GiB)
+    int64_t need = single ? (int64_t)h * h + (int64_t)h * h / 3 + 1024 : (int64_t)(CommInfo.d == 1 ? 8 : 12) * h * h + 4 * (int64_t)agg * agg + 4096;
     args.work.reserve(need);
 
     args.la_depth = 0;

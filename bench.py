@@ -300,10 +300,33 @@ def main():
                     best = (fname, fch, fmp, pr["ms_per_step"])
             except Exception as e:           # (a driver error raises on every rank alike: the grid agrees on status words)
                 comm_forms.append({"form": fname, "chunks": fch, "multipath": fmp, "error": repr(e)[:200]})
-        if best is not None and best[3] < 0.98 * r["ms_per_step"]:
-            name, chunks, mp = best[:3]
+        # second stage: the base-case order.  On a grid nothing runs beside the chain of base cases and small SUMMAs (the lookahead is a
+        # single-GPU device), and what a collective costs in latency on THIS node decides where the recursion should stop: with the best
+        # form so far, aggregated base cases of order 2048 and 4096 (one level, two levels fewer) get a probe each.
+        cur = best if (best is not None and best[3] < r["ms_per_step"]) else (name, chunks, mp, r["ms_per_step"])
+        best_bc = None
+        if args.bc is None and not pinned:
+            for order in (2 * BASE_CASE_ORDER, 4 * BASE_CASE_ORDER):
+                obc = bc_mult_for(n, d, c, order)
+                if obc == bc:
+                    continue
+                try:
+                    pr = time_cholesky(driver, L, h, n, c, obc, cur[1], 1, 1, distributed, device, bc_policy=0, multipath=cur[2])
+                    ok = max_over_ranks(pr["residual"], distributed, device) <= 1e-14
+                    comm_forms.append({"form": cur[0], "chunks": cur[1], "multipath": cur[2], "base_case_order": pr["stats"]["bc_dimension"],
+                                       "ms_per_step": pr["ms_per_step"], "residual": pr["residual"], "timed": "1 step", "valid": ok})
+                    if ok and pr["ms_per_step"] < cur[3] and (best_bc is None or pr["ms_per_step"] < best_bc[1]):
+                        best_bc = (obc, pr["ms_per_step"])
+                except Exception as e:
+                    comm_forms.append({"form": cur[0], "base_case_order": order, "error": repr(e)[:200]})
+        final_ms = best_bc[1] if best_bc else cur[3]
+        if final_ms < 0.98 * r["ms_per_step"]:
+            name, chunks, mp = cur[:3]
+            if best_bc:
+                bc = best_bc[0]
             r = time_cholesky(driver, L, h, n, c, bc, chunks, args.steps, args.warmup, distributed, device, bc_policy=0, multipath=mp)
-            comm_forms.append({"form": name, "chunks": chunks, "multipath": mp, "ms_per_step": r["ms_per_step"], "residual": r["residual"], "timed": "full"})
+            comm_forms.append({"form": name, "chunks": chunks, "multipath": mp, "base_case_order": r["stats"]["bc_dimension"],
+                               "ms_per_step": r["ms_per_step"], "residual": r["residual"], "timed": "full"})
         timer.cancel()
     residual_max = max_over_ranks(r["residual"], distributed, device)
     out = make_line(args, n, bc, r, chunks, mp, rccl, residual_max, comm_forms if distributed else None, recorded_traffic(n, args.gpus))

@@ -1045,9 +1045,6 @@ gemm_kernel_t pick_small(bool ak, bool bkc) {
 // waves covers the FULL width, so every element of the tall operand travels global -> LDS exactly once.
 constexpr int TSK_THREADS = 512, TSK_W = 256;    // up to 16 column strips of 16
 // the tall operands are read once and written once: non-temporal accesses (CAPI_TS_NT=0 compiles the plain ones, A/B)
-#ifndef CAPI_TS32_STAGE_IN_LOOP
-#define CAPI_TS32_STAGE_IN_LOOP 0
-#endif
 #ifndef CAPI_TS_NT
 #define CAPI_TS_NT 1
 #endif
@@ -1440,23 +1437,14 @@ __device__ __forceinline__ void trmm_ts32_body(const GemmArgs& p, double* __rest
       }
       cb0 = __builtin_amdgcn_mfma_f64_16x16x4f64(tb[s_], a0, cb0, 0, 0, 0);
       cb1 = __builtin_amdgcn_mfma_f64_16x16x4f64(tb[s_], a1, cb1, 0, 0, 0);
-#if CAPI_TS32_STAGE_IN_LOOP
-      // the next tile's eight LDS stores ride in the shadow of the last eight k-steps' MFMAs (its loads were issued a whole phase ago)
-      // instead of as a burst between the MFMA phase and the barrier (8 waves x 8 KB through a 128-byte/cycle port)
-      if (STEADY && s_ >= NB - 8) {
-        double* Ln = lds + (par ^ 1) * TILE;
-        const int q = s_ - (NB - 8);
-        Ln[lofs + 512 * q] = st[q].x; Ln[HALF + lofs + 512 * q] = st[q].y;
-      }
-#endif
     }
     __builtin_amdgcn_s_setprio(0);
     if (STEADY) {
-#if !CAPI_TS32_STAGE_IN_LOOP
+      // (spreading these eight LDS stores over the last eight k-steps' MFMAs instead -- the loads landed a whole phase earlier -- was
+      //  measured, build against build: p32->p32 4.64 -> 4.54 ms, cm->cm 4.99 -> 5.07, CholeskyQR2 18.99 -> 18.95 ms: nothing; r3k)
       double* Ln = lds + (par ^ 1) * TILE;
 #pragma unroll
       for (int q = 0; q < 8; ++q) { Ln[lofs + 512 * q] = st[q].x; Ln[HALF + lofs + 512 * q] = st[q].y; }
-#endif
     } else if (tile + dt < ntile) stage(lds + (par ^ 1) * TILE, tile + dt, st);
     par ^= 1;
     __syncthreads();

@@ -623,7 +623,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void dtrmm_pair_kernel(const GemmArgs 
 
   const int nblk = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, qq = nblk >> 3, rr = nblk & 7;
-  const int pid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const int pid = p.pid_base + (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);      // (pid_base: launch in resident rounds)
   const bool left = p.tri_side == CAPI_LEFT;
   const int ntri = left ? p.tiles_m : p.tiles_n, nfree = left ? p.tiles_n : p.tiles_m, npair = ntri >> 1;
   int pb, fr;
@@ -1824,6 +1824,24 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
       gemm_kernel_t kp = ak ? (bkc ? dtrmm_pair_kernel<true, true> : dtrmm_pair_kernel<true, false>)
                             : (bkc ? dtrmm_pair_kernel<false, true> : dtrmm_pair_kernel<false, false>);
       CAPI_RAISE_LDS_LIMIT(h, CAPI_ATTR_PAIR0 + (ak ? 2 : 0) + (bkc ? 1 : 0), kp, lds_bytes);
+      // Pairs do equal work, so a launch can go out one resident round (512 workgroups: an 8 x 8 block of pair-tiles per XCD) at a time
+      // at no cost in time, and every round's tiles start -- and, walking equal k-ranges, stay -- together: the panels an XCD's 64 tiles
+      // share are fetched once instead of once per drifting tile (CAPI_TRMM_PAIR_ROUNDS; measured in round 3).
+      static const int pair_rounds = getenv("CAPI_TRMM_PAIR_ROUNDS") ? atoi(getenv("CAPI_TRMM_PAIR_ROUNDS")) : 0;
+      if (pair_rounds && wgs > per_round) {
+        for (int64_t base = 0; base < wgs; base += per_round) {
+          GemmArgs q = p;
+          q.pid_base = (int)base;
+          capi_handle_s::prof_rec* rec;
+          int rc = prof_open((double)per_round / (double)wgs, rec);
+          if (rc != CAPI_OK) return rc;
+          if (rec) rec->variant += 16;
+          hipLaunchKernelGGL(kp, dim3((unsigned)per_round), dim3(NTHREADS), lds_bytes, s, q);
+          if (rec) CAPI_HIP_CHECK(h, hipEventRecord(rec->e1, s));
+        }
+        CAPI_HIP_CHECK(h, hipGetLastError());
+        return CAPI_OK;
+      }
       capi_handle_s::prof_rec* rec;
       int rc = prof_open(1.0, rec);
       if (rc != CAPI_OK) return rc;

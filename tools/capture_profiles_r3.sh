@@ -22,7 +22,7 @@ if [ $rc -eq 0 ]; then
   python tools/timed_region_stats.py $F 3 > $O/timed_region.txt; rc=$?
   cp $(find $O/tr -name "b_kernel_stats.csv" | head -1) $O/kernel_stats.csv
   cp $(find $O/tr -name "b_marker*stats*.csv" | head -1) $O/marker_stats.csv 2>/dev/null
-  python tools/gap_analysis.py $F > $O/gaps.txt 2>&1 || true
+  python tools/gap_analysis.py $F 4 > $O/gaps.txt 2>&1 || true        # W + K = 4 factor() calls of the headline
 fi
 rm -rf $O/tr; leg 2-kernel-trace $rc
 
@@ -49,7 +49,7 @@ import csv, collections
 rows = [r for r in csv.DictReader(open("$(find $O/pmc_trsm -name 'p_counter_collection.csv' | head -1)")) if r["Counter_Name"] == "FETCH_SIZE"]
 tot = collections.Counter(); cnt = collections.Counter()
 for r in rows:
-    k = r["Kernel_Name"].split("(")[0][-60:]
+    k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][-70:]
     tot[k] += float(r["Counter_Value"]) * 1024 * 2 / 1e9; cnt[k] += 1
 with open("$O/pmc_fe_trsm_mode_n65536.txt", "w") as f:
     f.write("TRSM-mode factor() at n = 65536 under rocprofv3 --pmc FETCH_SIZE, one process (tools/pmc_segv_probe.py 65536 1): 2 x FETCH_SIZE per kernel symbol, GB (launches)\n")

@@ -1756,10 +1756,11 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
   // tail is re-cut into 64-tiles (4x the workgroups, a quarter of the length) and launched right behind the full rounds.
   static const int rounds_mode = getenv("CAPI_ROUNDS") ? atoi(getenv("CAPI_ROUNDS")) : 0;
   const int64_t per_round = 2 * (int64_t)(h->cu_of[h->cur] ? h->cu_of[h->cur] : h->num_cu);
-  const bool use_rounds = rounds_mode > 0 && p.ts == 128 && p.splitk == 1 && !tri && p.out_uplo < 0 && per_round == 512 && p.batch <= 1 &&
-                          (int64_t)p.ntiles >= 2 * per_round;      // (see "Resident rounds" below)
+  // (bit 0: plain products; bit 1: triangular outputs in the banded order -- an XCD's 64 tiles of a round are an 8 x 8 block of the triangle)
+  const bool use_rounds = p.ts == 128 && p.splitk == 1 && !tri && per_round == 512 && p.batch <= 1 && (int64_t)p.ntiles >= 2 * per_round &&
+                          (p.out_uplo < 0 ? (rounds_mode & 1) != 0 : ((rounds_mode & 2) != 0 && (p.order & 1)));      // (see "Resident rounds" below)
   int tail128 = 0;
-  if (p.ts == 128 && p.splitk == 1 && !tri && !use_rounds && !getenv("CAPI_NO_TAIL")) {
+  if (p.ts == 128 && p.splitk == 1 && !tri && !getenv("CAPI_NO_TAIL")) {
     const int per_round = 2 * (h->cu_of[h->cur] ? h->cu_of[h->cur] : h->num_cu);
     const int rem = p.ntiles % per_round;
     if (p.ntiles >= 2 * per_round && rem > 0 && rem <= (3 * per_round) / 4) tail128 = rem;
@@ -1818,17 +1819,18 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
     // (CAPI_TRMM_PAIR=2: whenever the launch is whole rounds; =0: never); larger products keep the longest-first order.
     const int ntri_ = p.tri_side == CAPI_LEFT ? p.tiles_m : p.tiles_n, nfree_ = p.tri_side == CAPI_LEFT ? p.tiles_n : p.tiles_m;
     const int64_t wgs = (int64_t)(ntri_ / 2) * nfree_;
+    static const int pair_rounds = getenv("CAPI_TRMM_PAIR_ROUNDS") ? atoi(getenv("CAPI_TRMM_PAIR_ROUNDS")) : 0;
+    static const int pair_rounds_min = getenv("CAPI_TRMM_PAIR_ROUNDS_MIN") ? atoi(getenv("CAPI_TRMM_PAIR_ROUNDS_MIN")) : 0;
     if (pair_mode && tri && !p.tri_dense && !p.tri_block && p.tri_koff == 0 && p.ts == 128 && p.splitk == 1 && p.beta == 0.0 && p.batch <= 1 &&
         p.M % 128 == 0 && p.N % 128 == 0 && p.K % 128 == 0 && p.a_vec && p.b_vec && (ntri_ & 1) == 0 &&
-        wgs % per_round == 0 && (pair_mode > 1 || wgs <= 4 * per_round)) {
+        wgs % per_round == 0 && (pair_mode > 1 || wgs <= 4 * per_round || (pair_rounds && p.K >= pair_rounds_min))) {
       gemm_kernel_t kp = ak ? (bkc ? dtrmm_pair_kernel<true, true> : dtrmm_pair_kernel<true, false>)
                             : (bkc ? dtrmm_pair_kernel<false, true> : dtrmm_pair_kernel<false, false>);
       CAPI_RAISE_LDS_LIMIT(h, CAPI_ATTR_PAIR0 + (ak ? 2 : 0) + (bkc ? 1 : 0), kp, lds_bytes);
       // Pairs do equal work, so a launch can go out one resident round (512 workgroups: an 8 x 8 block of pair-tiles per XCD) at a time
       // at no cost in time, and every round's tiles start -- and, walking equal k-ranges, stay -- together: the panels an XCD's 64 tiles
       // share are fetched once instead of once per drifting tile (CAPI_TRMM_PAIR_ROUNDS; measured in round 3).
-      static const int pair_rounds = getenv("CAPI_TRMM_PAIR_ROUNDS") ? atoi(getenv("CAPI_TRMM_PAIR_ROUNDS")) : 0;
-      if (pair_rounds && wgs > per_round) {
+      if (pair_rounds && wgs > per_round && p.K >= pair_rounds_min) {
         for (int64_t base = 0; base < wgs; base += per_round) {
           GemmArgs q = p;
           q.pid_base = (int)base;

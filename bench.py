@@ -182,7 +182,7 @@ def make_line(args, n, bc, r, chunks, multipath, rccl, residual_max, comm_forms,
                    "n": n, "grid": r["grid"], "base_case_order": r["stats"]["bc_dimension"], "residual": residual_max,
                    "residual_is": "max over ranks of the reference validator (test/cholesky/validate.hpp:7-49)", "summa_chunks": chunks,
                    "multipath_pair_transfers": bool(multipath), "comm_forms": comm_forms,
-                   "launches_in_resident_rounds": os.environ.get("CAPI_ROUNDS", "0") != "0",
+                   "launches_in_resident_rounds": bool(r["grid"][0] * r["grid"][2] > 1 and not os.environ.get("CAPITAL_NO_LAUNCH_ROUNDS")) or os.environ.get("CAPI_ROUNDS", "0") != "0",
                    "rccl_world": list(rccl) if rccl else None},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
@@ -237,14 +237,6 @@ def main():
         raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank}, this node shows {torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if distributed:
-        # Grids run every product on ONE compute stream (the lookahead is a single-GPU device), so the large launches can go out one
-        # resident round at a time -- plain and triangular outputs (CAPI_ROUNDS=3), TRMMs in equal-work tile pairs (CAPI_TRMM_PAIR=2,
-        # CAPI_TRMM_PAIR_ROUNDS=1): same time, half the L2-to-fabric traffic (profiles/r3o_*, r3p_*: 3881 -> 1891 GB per factor() at n = 65536
-        # on one GPU), which on a grid is HBM / fabric bandwidth left to RCCL's copy kernels.  (On one GPU the rounds of the bulk streams
-        # interleave and stretch the per-launch durations the roofline figure is made of -- same step time, 0.91 -> 0.80 --, so they stay off there.)
-        for k, v in (("CAPI_ROUNDS", "3"), ("CAPI_TRMM_PAIR", "2"), ("CAPI_TRMM_PAIR_ROUNDS", "1")):
-            os.environ.setdefault(k, v)
     from capital_amd import capi, driver
     rccl = None
     if distributed:

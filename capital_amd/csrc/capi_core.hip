@@ -52,8 +52,27 @@ static int capi_create_common(capi_handle_t* out, int device, void* stream, bool
   return CAPI_OK;
 }
 
-int capi_create(capi_handle_t* h, int device) { return capi_create_common(h, device, nullptr, true); }
-int capi_create_on_stream(capi_handle_t* h, int device, void* s) { return capi_create_common(h, device, s, false); }
+static void rounds_defaults(capi_handle_t h) {
+  const char* e;
+  h->rounds_env[0] = (e = getenv("CAPI_ROUNDS")) ? atoi(e) : 0;
+  h->rounds_env[1] = (e = getenv("CAPI_TRMM_PAIR")) ? atoi(e) : 1;
+  h->rounds_env[2] = (e = getenv("CAPI_TRMM_PAIR_ROUNDS")) ? atoi(e) : 0;
+  h->rounds_env[3] = (e = getenv("CAPI_TRMM_PAIR_ROUNDS_MIN")) ? atoi(e) : 0;
+  h->rounds_mode = h->rounds_env[0]; h->pair_mode = h->rounds_env[1]; h->pair_rounds = h->rounds_env[2]; h->pair_rounds_min = h->rounds_env[3];
+}
+int capi_create(capi_handle_t* h, int device) { int rc = capi_create_common(h, device, nullptr, true); if (rc == CAPI_OK) rounds_defaults(*h); return rc; }
+int capi_create_on_stream(capi_handle_t* h, int device, void* s) { int rc = capi_create_common(h, device, s, false); if (rc == CAPI_OK) rounds_defaults(*h); return rc; }
+
+// on = 1: every large launch of this handle goes out one resident round at a time (plain and triangular outputs, TRMMs as equal-work tile
+// pairs); on = 0: back to the handle's defaults (environment).  For callers whose products all run on ONE stream (grids; the TRSM mode):
+// same time, about half the L2-to-fabric traffic.  Returns the previous setting through *was (may be NULL).
+int capi_set_launch_rounds(capi_handle_t h, int on, int* was) {
+  CAPI_REQUIRE(h, h && (on == 0 || on == 1), "args");
+  if (was) *was = (h->rounds_mode == 3 && h->pair_mode == 2 && h->pair_rounds == 1 && h->pair_rounds_min == 0) ? 1 : 0;
+  if (on) { h->rounds_mode = 3; h->pair_mode = 2; h->pair_rounds = 1; h->pair_rounds_min = 0; }
+  else { h->rounds_mode = h->rounds_env[0]; h->pair_mode = h->rounds_env[1]; h->pair_rounds = h->rounds_env[2]; h->pair_rounds_min = h->rounds_env[3]; }
+  return CAPI_OK;
+}
 
 int capi_destroy(capi_handle_t h) {
   if (!h) return CAPI_EINVAL;

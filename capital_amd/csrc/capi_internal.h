@@ -48,6 +48,11 @@ struct capi_handle_s {
   struct graph_ent { int64_t n, lda, ldx; double *A, *X; void* w; hipStream_t s; hipGraphExec_t exec; int seen; };
   graph_ent* graphs = nullptr;
   int graphs_n = 0, graphs_cap = 0;
+  // large launches one resident round (2 x CUs workgroups) at a time -- capi_set_launch_rounds; the environment gives the defaults
+  // (CAPI_ROUNDS: bit 0 plain products, bit 1 triangular outputs; CAPI_TRMM_PAIR: 0 never / 1 up to four whole rounds / 2 every whole-round
+  // launch in tile pairs; CAPI_TRMM_PAIR_ROUNDS: pairs one round per launch, from K = CAPI_TRMM_PAIR_ROUNDS_MIN up)
+  int rounds_mode = 0, pair_mode = 1, pair_rounds = 0, pair_rounds_min = 0;
+  int rounds_env[4] = {0, 1, 0, 0};
   char err[512] = {0};
 };
 

@@ -1754,7 +1754,7 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
   // A 128-tiling fills the chip in rounds of 2 x CUs workgroups; the last round is usually partial and its lone
   // workgroups run at ~0.6 of the paired rate (8256 tiles = 16 rounds + 64: those 64 cost almost another round).  The
   // tail is re-cut into 64-tiles (4x the workgroups, a quarter of the length) and launched right behind the full rounds.
-  static const int rounds_mode = getenv("CAPI_ROUNDS") ? atoi(getenv("CAPI_ROUNDS")) : 0;
+  const int rounds_mode = h->rounds_mode;
   const int64_t per_round = 2 * (int64_t)(h->cu_of[h->cur] ? h->cu_of[h->cur] : h->num_cu);
   // (bit 0: plain products; bit 1: triangular outputs in the banded order -- an XCD's 64 tiles of a round are an 8 x 8 block of the triangle)
   const bool use_rounds = p.ts == 128 && p.splitk == 1 && !tri && per_round == 512 && p.batch <= 1 && (int64_t)p.ntiles >= 2 * per_round &&
@@ -1811,7 +1811,7 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
   // bulk stream queue behind the chain's kernels at every boundary (0.876 -> 0.825 on the same box).
   // TRMM in tile pairs (dtrmm_pair_kernel): equal work per workgroup, the launch of a plain product
   {
-    static const int pair_mode = getenv("CAPI_TRMM_PAIR") ? atoi(getenv("CAPI_TRMM_PAIR")) : 1;
+    const int pair_mode = h->pair_mode;
     // Measured (tools/pair_window.py, all three forms of the recursion): a launch of exactly one resident round +8..10 % (order 4096:
     // 63 -> 68.5 TFLOP/s; 2048 x 8192: 51..55 -> 55..59), two rounds +2..3 %, four +0.5..1 %, nine +-0.5 %; a launch that is NOT whole
     // rounds loses (1152 workgroups, order 6144: 68.3 -> 61.5 -- the equal, long workgroups of the last 128 cost a third round).
@@ -1819,8 +1819,7 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
     // (CAPI_TRMM_PAIR=2: whenever the launch is whole rounds; =0: never); larger products keep the longest-first order.
     const int ntri_ = p.tri_side == CAPI_LEFT ? p.tiles_m : p.tiles_n, nfree_ = p.tri_side == CAPI_LEFT ? p.tiles_n : p.tiles_m;
     const int64_t wgs = (int64_t)(ntri_ / 2) * nfree_;
-    static const int pair_rounds = getenv("CAPI_TRMM_PAIR_ROUNDS") ? atoi(getenv("CAPI_TRMM_PAIR_ROUNDS")) : 0;
-    static const int pair_rounds_min = getenv("CAPI_TRMM_PAIR_ROUNDS_MIN") ? atoi(getenv("CAPI_TRMM_PAIR_ROUNDS_MIN")) : 0;
+    const int pair_rounds = h->pair_rounds, pair_rounds_min = h->pair_rounds_min;
     if (pair_mode && tri && !p.tri_dense && !p.tri_block && p.tri_koff == 0 && p.ts == 128 && p.splitk == 1 && p.beta == 0.0 && p.batch <= 1 &&
         p.M % 128 == 0 && p.N % 128 == 0 && p.K % 128 == 0 && p.a_vec && p.b_vec && (ntri_ & 1) == 0 &&
         wgs % per_round == 0 && (pair_mode > 1 || wgs <= 4 * per_round || (pair_rounds && p.K >= pair_rounds_min))) {

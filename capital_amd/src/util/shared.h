@@ -105,6 +105,19 @@ inline void dev_copy(double* dst, const double* src, int64_t count) {
   CAPITAL_CHECK(capi_memcpy_d2d_async(handle(), dst, src, sizeof(double) * (size_t)count));
 }
 
+// Scope in which every large launch of the handle goes out one resident round at a time (capi_set_launch_rounds): for schedules whose
+// products all run on ONE stream -- grids (the lookahead is a single-GPU device), the TRSM mode.  CAPITAL_NO_LAUNCH_ROUNDS keeps the defaults.
+struct launch_rounds_scope {
+  int was = 0;
+  bool active = false;
+  explicit launch_rounds_scope(bool on) {
+    if (on && !getenv("CAPITAL_NO_LAUNCH_ROUNDS")) { check(capi_set_launch_rounds(handle(), 1, &was), "capi_set_launch_rounds"); active = true; }
+  }
+  launch_rounds_scope(const launch_rounds_scope&) = delete;
+  launch_rounds_scope& operator=(const launch_rounds_scope&) = delete;
+  ~launch_rounds_scope() { if (active && !was && ctx().handle) (void)capi_set_launch_rounds(ctx().handle, 0, nullptr); }
+};
+
 // How many ranks of `comm` hold a non-zero status word (collective over comm; one 8-byte all-reduce and one 8-byte read).
 // An error that only some ranks can see -- the base-case policies that factor on layer 0 or on the slice root alone
 // (policy.h:226-514) -- must unwind every rank or none: a rank that throws while its peers go on leaves them hanging in

@@ -60,6 +60,11 @@ int  capi_sync(capi_handle_t h);
 int  capi_reserve_workspace(capi_handle_t h, size_t bytes);
 /* release every private workspace block of the handle (synchronises); they are re-created on demand */
 int  capi_trim_workspaces(capi_handle_t h);
+/* on = 1: every large launch of the handle goes out one resident round (2 x CUs workgroups: an 8 x 8 block of tiles per XCD) at a time --
+ * plain and triangular outputs, TRMMs as equal-work tile pairs: same time, about half the L2-to-fabric traffic, for callers whose products
+ * all run on one stream (grids, the TRSM mode); on = 0: the handle's defaults (environment: CAPI_ROUNDS, CAPI_TRMM_PAIR, CAPI_TRMM_PAIR_ROUNDS).
+ * *was (may be NULL) receives the previous setting. */
+int  capi_set_launch_rounds(capi_handle_t h, int on, int* was);
 
 /* ---- BLAS layer: replaces blas::engine::_gemm/_trmm/_syrk (src/blas/interface.h:58-66,
  *      src/blas/interface.hpp:43-97 -> cblas_dgemm/dtrmm/dsyrk) ---- */

@@ -337,6 +337,7 @@ int capi_pairs_transfer(capi_comm_t c, const int* dst, const double* send, doubl
 }
 int capi_comm_query(capi_comm_t c, int* r, int* s) { if (!c) return CAPI_EINVAL; *r = c->me; *s = (int)c->ranks.size(); return 0; }
 int capi_trim_workspaces(capi_handle_t) { return 0; }
+int capi_set_launch_rounds(capi_handle_t, int, int* was) { if (was) *was = 0; return 0; }
 int capi_range_push(const char*) { return 0; }
 int capi_range_pop(void) { return 0; }
 int capi_sendrecv_replace(capi_comm_t c, double* buf, int64_t count, int peer, double* staging) {

@@ -122,6 +122,11 @@ def recorded_traffic(n, gpus):
 
 def time_cholesky(driver, L, h, n, c, bc, chunks, steps, warmup, distributed, device, bc_policy, trsm_mode=False, multipath=None):
     if multipath is not None:          # read by topo::square when the grid object is built (capital_amd/src/util/topology.h)
+        # "kslice": the replicated 2-GPU grid by K-slices + depth all-reduce instead of by output columns (summa.h: colsplit)
+        os.environ.pop("CAPITAL_KSLICE", None)
+        if multipath == "kslice":
+            os.environ["CAPITAL_KSLICE"] = "1"
+            multipath = False
         os.environ["CAPITAL_MULTIPATH"] = "1" if multipath else "0"
     prob = driver.Cholinv(n, c=c, complete_inv=0, split=1, bc_mult=bc, layout=0, num_chunks=chunks, serialize=True, bc_policy=bc_policy, trsm_mode=trsm_mode)
     prob.generate()
@@ -181,7 +186,7 @@ def make_line(args, n, bc, r, chunks, multipath, rccl, residual_max, comm_forms,
                                f"{r['grid'][0]}x{r['grid'][1]}x{r['grid'][2]} GPU grid" + (" = BASELINE config 4" if args.gpus == 8 and n == 65536 else ""),
                    "n": n, "grid": r["grid"], "base_case_order": r["stats"]["bc_dimension"], "residual": residual_max,
                    "residual_is": "max over ranks of the reference validator (test/cholesky/validate.hpp:7-49)", "summa_chunks": chunks,
-                   "multipath_pair_transfers": bool(multipath), "comm_forms": comm_forms,
+                   "multipath_pair_transfers": multipath is True, "comm_forms": comm_forms,
                    "launches_in_resident_rounds": bool(r["grid"][0] * r["grid"][2] > 1 and not os.environ.get("CAPITAL_NO_LAUNCH_ROUNDS")) or os.environ.get("CAPI_ROUNDS", "0") != "0",
                    "rccl_world": list(rccl) if rccl else None},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -269,6 +274,8 @@ def main():
         forms += [("chunks4", 4, False), ("chunks8", 8, False)]
         if args.gpus >= 4:
             forms += [("multipath", 0, True), ("multipath+chunks4", 4, True), ("multipath+chunks8", 8, True)]
+        else:
+            forms += [("kslice", 0, "kslice"), ("kslice+chunks4", 4, "kslice")]
     pinned = os.environ.get("CAPITAL_BENCH_FORM")
     if pinned:
         forms = [f for f in forms if f[0] == pinned] or forms[:1]

@@ -112,6 +112,15 @@ public:
       CAPITAL_CHECK(capi_dgemm(h, transA, transB, M, N, K, alpha, A.p, A.ld, B.p, B.ld, beta, C.p, C.ld));
       return;
     }
+    if (t.d == 1 && colsplit() && transB == CAPI_NOTRANS) {
+      // replicated layers: layer z forms C[:, b_z : b_z+1) = alpha op(A) B[:, b_z : b_z+1) + beta C[:, ...) in place, then the blocks travel
+      colsplit_run(t, N, false, C.p, C.ld,
+                   [&](int64_t c0, int64_t c1) {
+                     CAPITAL_CHECK(capi_dgemm(h, transA, CAPI_NOTRANS, M, c1 - c0, K, alpha, A.p, A.ld, B.p + c0 * B.ld, B.ld, beta, C.p + c0 * C.ld, C.ld));
+                   },
+                   [&](int64_t) { return M; }, ws);
+      return;
+    }
     const int64_t mark = ws.top;
     view acc = t.c > 1 ? view{ws.take(M * N), M, M, N} : C;
     const size_t steps = t.d > 1 ? t.d / t.c : 1;
@@ -243,9 +252,27 @@ public:
       CAPITAL_CHECK(capi_dtrmm_oop(h, side, uplo, trans, diag, M, N, alpha, T.p, T.ld, B.p, B.ld, Cout.p, Cout.ld));
       return;
     }
+    const bool eff_upper = (uplo == CAPI_UPPER) != (trans == CAPI_TRANS);
+    if (t.d == 1 && colsplit() && (side == CAPI_LEFT || (eff_upper && trans == CAPI_NOTRANS))) {
+      // replicated layers, by output columns.  Left: Cout[:, cols] = alpha op(T) B[:, cols].  Right with an upper, untransposed T: column j
+      // of the product only meets rows <= j of T: Cout[:, c0:c1) = alpha ( B[:, 0:c0) T[0:c0, c0:c1) + B[:, c0:c1) T[c0:c1, c0:c1) )
+      colsplit_run(t, N, side == CAPI_RIGHT, Cout.p, Cout.ld,
+                   [&](int64_t c0, int64_t c1) {
+                     double* Cj = Cout.p + c0 * Cout.ld;
+                     if (side == CAPI_LEFT) {
+                       CAPITAL_CHECK(capi_dtrmm_oop(h, side, uplo, trans, diag, M, c1 - c0, alpha, T.p, T.ld, B.p + c0 * B.ld, B.ld, Cj, Cout.ld));
+                     } else {
+                       if (c0 > 0)
+                         CAPITAL_CHECK(capi_dgemm(h, CAPI_NOTRANS, CAPI_NOTRANS, M, c1 - c0, c0, alpha, B.p, B.ld, T.p + c0 * T.ld, T.ld, 0.0, Cj, Cout.ld));
+                       CAPITAL_CHECK(capi_dtrmm_acc(h, side, uplo, trans, diag, M, c1 - c0, alpha, T.p + c0 + c0 * T.ld, T.ld, B.p + c0 * B.ld, B.ld,
+                                                    c0 > 0 ? 1.0 : 0.0, Cj, Cout.ld));
+                     }
+                   },
+                   [&](int64_t) { return M; }, ws);
+      return;
+    }
     const int64_t mark = ws.top;
     const size_t steps = t.d > 1 ? t.d / t.c : 1;
-    const bool eff_upper = (uplo == CAPI_UPPER) != (trans == CAPI_TRANS);
     // The output-column pipeline serves the one-step cases (c == d as in the reference, or d == 1): every left multiply, and the
     // right multiply with an upper, untransposed T (the inverse completion, cholinv.hpp:150-154; cacqr.hpp:108-112) -- there column
     // chunk j of the output needs B's column chunks 0..j, which arrive in that order.
@@ -387,6 +414,20 @@ public:
       CAPITAL_CHECK(capi_dgemmt(h, uplo, tA, tB, N, K, alpha, L.p, L.ld, Rr.p, Rr.ld, beta, C.p, C.ld));
       return;
     }
+    if (t.d == 1 && colsplit() && trans && uplo == CAPI_UPPER) {
+      // replicated layers: layer z forms its column range of the upper triangle in place (the rectangle above the range's diagonal block +
+      // the block), rows 0 .. c1 of those columns travel
+      colsplit_run(t, N, true, C.p, C.ld,
+                   [&](int64_t c0, int64_t c1) {
+                     const double* rj = A.p + c0 * A.ld;
+                     if (c0 > 0)
+                       CAPITAL_CHECK(capi_dgemm(h, CAPI_TRANS, CAPI_NOTRANS, c0, c1 - c0, K, alpha, Bx.p, Bx.ld, rj, A.ld, beta, C.p + c0 * C.ld, C.ld));
+                     CAPITAL_CHECK(capi_dgemmt(h, CAPI_UPPER, CAPI_TRANS, CAPI_NOTRANS, c1 - c0, K, alpha, Bx.p + c0 * Bx.ld, Bx.ld, rj, A.ld, beta,
+                                               C.p + c0 + c0 * C.ld, C.ld));
+                   },
+                   [&](int64_t c1) { return c1; }, ws);
+      return;
+    }
     const int64_t mark = ws.top;
     const size_t steps = t.d > 1 ? t.d / t.c : 1;
     // the pipeline is built for what cholinv issues: upper triangle, transposed form, one K-class per layer
@@ -499,6 +540,75 @@ public:
     int64_t per = ((K + (int64_t)c - 1) / (int64_t)c + 1) & ~(int64_t)1;
     k0 = std::min<int64_t>(K, per * (int64_t)z);
     k1 = std::min<int64_t>(K, k0 + per);
+  }
+
+  // ---- replicated layers (d == 1, c > 1: the 2-GPU grid) by OUTPUT COLUMNS ------------------------------------------------------------
+  // Every layer holds the whole operands.  Round 2 sliced the K range and all-reduced the full outputs over `depth` (h^2 doubles in each
+  // direction per product, plus an accumulator and an add pass).  Here layer z computes the output columns [b_z, b_z+1) -- all of K, in
+  // place, with the caller's beta -- and the blocks are exchanged (c broadcasts over `depth`, both directions of the link at once with
+  // c = 2): half the bytes of the all-reduce, no accumulator, and every element is computed exactly once, by the kernel and in the
+  // summation order of the single-GPU run.  Triangular work (a TRMM with the triangle on the right, a triangular output) grows linearly
+  // with the column index, so the boundaries sit at N sqrt(z / c).  CAPITAL_KSLICE=1 restores the K-slicing (A/B).
+  static bool colsplit() { return getenv("CAPITAL_KSLICE") == nullptr; }      // (read per multiply: bench.py probes both forms in one process)
+  static int64_t colsplit_bound(int64_t N, size_t c, size_t z, bool triangular) {
+    if (z == 0) return 0;
+    if (z >= c) return N;
+    const double f = triangular ? std::sqrt((double)z / (double)c) : (double)z / (double)c;
+    const int64_t b = ((int64_t)std::llround(f * (double)N) + 1) & ~(int64_t)1;
+    return std::min<int64_t>(N, std::max<int64_t>(0, b));
+  }
+  // compute(c0, c1) enqueues the kernels that finish output columns [c0, c1) in place at `base` (leading dimension ld); rows_of(c1) = how
+  // many leading rows of those columns carry the result (all of them, or c1 for an upper-triangular output).  With num_chunks > 0 the
+  // exchange of chunk j (communication stream) runs beside the computation of chunk j + 1.
+  template <typename CommType, typename Compute, typename RowsOf>
+  static void colsplit_run(CommType&& t, int64_t N, bool triangular, double* base, int64_t ld, Compute&& compute, RowsOf&& rows_of, arena& ws) {
+    capi_handle_t h = capital::handle();
+    const int64_t mark = ws.top;
+    std::vector<int64_t> b(t.c + 1);
+    int64_t widest = 0;
+    for (size_t z = 0; z <= t.c; ++z) b[z] = colsplit_bound(N, t.c, z, triangular);
+    for (size_t z = 0; z < t.c; ++z) widest = std::max(widest, b[z + 1] - b[z]);
+    const int nch = t.num_chunks > 0 ? chunk_count(t.num_chunks, widest) : 1;
+    pipe P(nch > 1);
+    enum { EC = 70, ER = 140 };
+    double* tmp = nullptr;                                       // staging of a strided block (allocated once: it is used on the communication stream)
+    int64_t tmp_need = 0;
+    for (size_t z = 0; z < t.c; ++z)
+      for (int j = 0; j < nch; ++j) {
+        int64_t c0, c1;
+        chunk_range(b[z + 1] - b[z], nch, j, c0, c1);
+        const int64_t rows = rows_of(b[z] + c1);
+        if (rows != ld) tmp_need = std::max(tmp_need, rows * (c1 - c0));
+      }
+    if (tmp_need > 0) tmp = ws.take(tmp_need);
+    P.main();
+    for (int j = 0; j < nch; ++j) {
+      int64_t c0, c1;
+      chunk_range(b[t.z + 1] - b[t.z], nch, j, c0, c1);
+      if (c1 > c0) compute(b[t.z] + c0, b[t.z] + c1);
+      P.rec(EC + j);
+    }
+    P.comm();
+    for (int j = 0; j < nch; ++j) {
+      P.wait(EC + j);
+      for (size_t z = 0; z < t.c; ++z) {
+        int64_t c0, c1;
+        chunk_range(b[z + 1] - b[z], nch, j, c0, c1);
+        if (c1 <= c0) continue;
+        const int64_t g0 = b[z] + c0, g1 = b[z] + c1, rows = rows_of(g1);
+        double* blk = base + g0 * ld;
+        if (rows == ld) {
+          CAPITAL_CHECK(capi_bcast(t.depth, blk, rows * (g1 - g0), (int)z));
+        } else {
+          if (t.z == z) CAPITAL_CHECK(capi_dlacpy(h, 0, rows, g1 - g0, blk, ld, tmp, rows));
+          CAPITAL_CHECK(capi_bcast(t.depth, tmp, rows * (g1 - g0), (int)z));
+          if (t.z != z) CAPITAL_CHECK(capi_dlacpy(h, 0, rows, g1 - g0, tmp, rows, blk, ld));
+        }
+      }
+    }
+    P.rec(ER);
+    P.main(); P.wait(ER);
+    ws.top = mark;
   }
 
   enum { AX_ROW = 0, AX_COLUMN = 1 };

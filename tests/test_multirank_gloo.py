@@ -30,7 +30,7 @@ def _free_port():
     return p
 
 
-def _launch(world, cfg, timeout=600, multipath=True):
+def _launch(world, cfg, timeout=600, multipath=True, extra_env=None):
     """multipath: grids of pairs (2x2x1, 2x2x2) send every pair broadcast / depth all-reduce / partner exchange through
     capi_pairs_transfer with a threshold of 8 doubles, so the relayed two-phase path (csrc/pair_paths.h) carries even these small
     messages; False = the per-pair collectives on the sub-communicators."""
@@ -40,6 +40,7 @@ def _launch(world, cfg, timeout=600, multipath=True):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    OMP_NUM_THREADS="1", GLOO_SOCKET_IFNAME="lo", CAPITAL_MIN_CHUNK_COLS="8",
                    CAPITAL_MULTIPATH="2" if multipath else "0", CAPITAL_MULTIPATH_MIN="8")
+        env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable, os.path.join(SHIM, "rank_main.py"), json.dumps(cfg)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -72,15 +73,19 @@ def _launch(world, cfg, timeout=600, multipath=True):
     (8, 2, 200, -2, 1, True, (3, 3)),
     (8, 2, 192, -2, 1, True, (0, 3, "plain")),   # the same pipeline over the per-pair RCCL collectives (multi-path off)
     (4, 1, 128, -1, 1, False, (0, 0, "plain")),
+    (2, 2, 160, -2, 1, True, (0, 0, "kslice")),    # the replicated 2-rank grid by K-slices + depth all-reduce (round 2's form; default now: by output columns)
+    (2, 2, 130, -2, 1, False, (1, 3, "kslice")),
+    (2, 2, 200, -3, 1, True, (2, 5)),              # column split with the chunk pipeline, ragged chunk widths
 ])
 def test_cholinv_on_grids(oracle, shim_lib, world, c, n, bc, ci, serialize, policy):
-    chunks, multipath = 0, True
+    chunks, multipath, extra = 0, True, {}
     if isinstance(policy, tuple):
-        multipath = len(policy) < 3
+        multipath = not (len(policy) == 3 and policy[2] == "plain")
+        extra = {"CAPITAL_KSLICE": "1"} if (len(policy) == 3 and policy[2] == "kslice") else {}
         policy, chunks = policy[0], policy[1]
     with tempfile.TemporaryDirectory() as d:
         _launch(world, {"kind": "cholinv", "n": n, "c": c, "bc": bc, "ci": ci, "serialize": serialize, "policy": policy, "chunks": chunks, "dir": d},
-                multipath=multipath)
+                multipath=multipath, extra_env=extra)
         A = oracle.distribute_symmetric(n, n, 0, 0, 1, 1)
         Rg, Ig = np.zeros((n, n), order="F"), np.zeros((n, n), order="F")
         levels = set()

@@ -82,8 +82,25 @@ def lib():
         L.orc_qr_orthogonality.restype = _dbl
         L.orc_set_threads.argtypes = [_int]
         L.orc_get_threads.restype = _int
+        # OpenMP's default is one thread per hardware thread the affinity mask lists -- 128 on a one-GPU box whose cgroup share is 16 cores:
+        # the checker then spins instead of computing (a 2-rank parity run of nine n = 4096 cases went from ~1 to > 8 minutes when nothing
+        # else in the process had tamed the runtime first).  Cap it at the share unless the caller chose (OMP_NUM_THREADS).
+        if not os.environ.get("OMP_NUM_THREADS"):
+            L.orc_set_threads(_cpu_share())
         _lib = L
     return _lib
+
+
+def _cpu_share():
+    """cores this process may really use: cgroup CPU quota, else the affinity mask; at most 16 (see oracle/host_baseline.py)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
 
 
 def _p(a):

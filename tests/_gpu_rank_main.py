@@ -18,7 +18,9 @@ def main():
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(local)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # a rank that dies must not leave its peers in gloo's 30-minute default wait
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=int(os.environ.get("CAPITAL_TEST_GLOO_TIMEOUT_S", "300"))))
     from capital_amd import driver
     driver.init_distributed(local)
     rr, rs = driver.world_query() if world > 1 or os.environ.get("CAPI_RCCL_FORCE") else (rank, world)
@@ -28,6 +30,7 @@ def main():
         for k in ("CAPITAL_MULTIPATH", "CAPITAL_MULTIPATH_MIN"):       # per-case switches, read when the grid object is built
             os.environ.pop(k, None)
         os.environ.update(case.get("env", {}))
+        print(f"rank {rank}: case {tag} starts", flush=True)
         if case["kind"] == "cholinv":
             p = driver.Cholinv(case["n"], c=case["c"], complete_inv=case["ci"], split=1, bc_mult=case["bc"], layout=case.get("layout", 0),
                                num_chunks=case.get("chunks", 0), serialize=case["serialize"], bc_policy=case["policy"], trsm_mode=case.get("trsm", False))

@@ -39,7 +39,7 @@ def _free_port():
 LOOPBACK = os.path.join(HERE, "rccl_loopback", "librccl_loopback.so")
 
 
-def _launch(world, cfg, timeout=900, loopback=False):
+def _launch(world, cfg, timeout=int(os.environ.get("CAPITAL_TEST_RANK_TIMEOUT_S", "900")), loopback=False):
     port = _free_port()
     procs = []
     for r in range(world):
@@ -49,18 +49,26 @@ def _launch(world, cfg, timeout=900, loopback=False):
             env["CAPI_RCCL_FORCE"] = "1"
         if loopback:
             env["CAPI_RCCL_LIB"] = LOOPBACK
-        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_gpu_rank_main.py"), json.dumps(cfg)], env=env,
-                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+        logdir = os.environ.get("CAPITAL_TEST_RANK_LOG_DIR")        # diagnostics: every rank's output into a file that survives a killed run
+        out = open(os.path.join(logdir, f"rank{r}_of{world}{'_loopback' if loopback else ''}.log"), "w") if logdir else subprocess.PIPE
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.join(HERE, "_gpu_rank_main.py"), json.dumps(cfg)], env=env,
+                                      stdout=out, stderr=subprocess.STDOUT, text=True))
     outs = []
+    timed_out = False
     try:
         for p in procs:
             o, _ = p.communicate(timeout=timeout)
             outs.append(o)
+    except subprocess.TimeoutExpired:
+        timed_out = True
     finally:
         for p in procs:
             if p.poll() is None:
                 p.kill()
-    assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
+    if timed_out:                                       # what every rank had printed when the limit struck (each case announces itself)
+        outs = [p.communicate()[0] or "" for p in procs]
+    outs = [o or "" for o in outs]
+    assert not timed_out and all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
 
 
 # N -> c of the d x d x c grid: 1 = 1x1x1, 2 = 1x1x2 (K-slicing), 4 = 2x2x1 (two K-classes per layer), 8 = 2x2x2 (the reference's cubic case)

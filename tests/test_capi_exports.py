@@ -73,3 +73,15 @@ def test_comm_size_one_needs_no_rccl():
     assert L.capi_comm_split(None, 0, 0, C.byref(out)) != 0
     r = C.c_int()
     assert L.capi_comm_rank(None, C.byref(r)) != 0
+
+
+def test_pairs_transfer_rejects_bad_arguments_without_a_gpu():
+    """capi_pairs_transfer / capi_pairs_scratch_count are pure host logic up to the first RCCL call: null arguments fail cleanly, the relay
+    space is what csrc/pair_paths.h says (one unit per rank, units of even length), and 2-rank nodes need none."""
+    from capital_amd import capi
+    L = capi.load()
+    assert L.capi_pairs_transfer(None, None, None, None, 8, None) != 0
+    assert L.capi_pairs_scratch_count(2, 1 << 20) == 0
+    u = ((1001 + 7) // 8 + 1) // 2 * 2
+    assert L.capi_pairs_scratch_count(8, 1001) == 8 * u
+    assert L.capi_pairs_scratch_count(4, 4096) == 4 * 1024

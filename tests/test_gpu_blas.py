@@ -471,3 +471,32 @@ def test_randomized_shapes_against_numpy(hip):
             _check(got[:m, :], ref, nt, np.abs(ref).max() + 1.0)
         if pad:
             np.testing.assert_array_equal(got[m:, :], Cf[m:, :])
+
+
+@pytest.mark.gpu
+def test_panel32_entry_points_reject_what_they_cannot_serve(hip):
+    """The panel32 forms exist for ONE shape family (n = 256, whole 32-row tiles, tall): everything else must come back as an argument error
+    with a message, not run a kernel on a layout it does not understand."""
+    import torch
+    from capital_amd import capi
+    n, m = 256, 32 * 1024
+    A = torch.zeros((m // 32, n, 32), dtype=torch.float64, device="cuda")
+    G = torch.zeros((n, n), dtype=torch.float64, device="cuda")
+    T = torch.eye(n, dtype=torch.float64, device="cuda")
+    L = capi.load()
+    h = hip.h
+    import ctypes as C
+    d = C.c_double
+    assert L.capi_dsyrk_panel32(h, 128, m, d(1.0), capi.ptr(A), d(0.0), capi.ptr(G), n) != 0            # n != 256
+    assert L.capi_dsyrk_panel32(h, n, m + 16, d(1.0), capi.ptr(A), d(0.0), capi.ptr(G), n) != 0         # k not a multiple of 32
+    assert L.capi_dsyrk_panel32(h, n, 32 * 100, d(1.0), capi.ptr(A), d(0.0), capi.ptr(G), n) != 0       # not tall (k < 64 n)
+    assert L.capi_dsyrk_panel32(h, n, m, d(1.0), capi.ptr(A), d(0.0), capi.ptr(G), n - 1) != 0          # ldc < n
+    assert b"panel32" in L.capi_last_error(h) or b"operands" in L.capi_last_error(h)
+    assert L.capi_dtrmm_right_panel32(h, m + 8, n, d(1.0), capi.ptr(T), n, capi.ptr(A), 0, capi.ptr(A), 0) != 0     # ragged m, and C aliases B
+    assert L.capi_dtrmm_right_panel32(h, m, n, d(1.0), capi.ptr(T), n, capi.ptr(A), 0, capi.ptr(A), 0) != 0         # C aliases B
+    assert L.capi_dtrmm_right_panel32(h, m, n, d(1.0), capi.ptr(T), n - 1, capi.ptr(A), 0, capi.ptr(G), 0) != 0     # ldt < n
+    # and the rounds switch hands back what was set before
+    was = C.c_int(-1)
+    assert L.capi_set_launch_rounds(h, 1, C.byref(was)) == 0 and was.value == 0
+    assert L.capi_set_launch_rounds(h, 0, C.byref(was)) == 0 and was.value == 1
+    assert L.capi_set_launch_rounds(h, 2, None) != 0

@@ -294,7 +294,14 @@ int capi_pairs_transfer(capi_comm_t c, const int* dst, const double* send, doubl
     void recv(double* p, int64_t n, int peer) { NCCL_IN_GROUP(c, first, g_rccl.Recv(p, (size_t)n, ncclDouble, peer, c->comm, c->h->stream)); }
     int group_end() { return group_result(c, first, "capi_pairs_transfer"); }
   };
-  if (!c->comm) return (c->size == 1 && dst[0] < 0) ? CAPI_OK : CAPI_EINVAL;     // a lone rank has nobody to send to
+  if (!c->comm) {                                                                  // a lone rank that never touched RCCL: nothing, or a local copy to itself
+    if (c->size != 1 || dst[0] > 0) return CAPI_EINVAL;
+    if (dst[0] == 0 && count > 0) {
+      if (!send || !recv) return CAPI_EINVAL;
+      if (send != recv) CAPI_HIP_CHECK(c->h, hipMemcpyAsync(recv, send, sizeof(double) * count, hipMemcpyDeviceToDevice, c->h->stream));
+    }
+    return CAPI_OK;
+  }
   static const int64_t min_count = getenv("CAPITAL_MULTIPATH_MIN") ? atoll(getenv("CAPITAL_MULTIPATH_MIN")) : ((int64_t)1 << 20);
   RcclPaths x{c};
   const int rc = pair_paths::transfer(x, c->rank, c->size, dst, send, recv, count, scratch, min_count);

@@ -30,7 +30,8 @@ inline int64_t unit_len(int64_t count, int n) {
 inline int64_t scratch_count(int n, int64_t count) { return n <= 2 ? 0 : (int64_t)n * unit_len(count, n); }
 
 // dst[r], r = 0 .. n-1 (the same array on every rank): the rank that r sends its `count` doubles to, or -1.  No rank is the
-// destination of two transfers and nobody sends to itself.  Returns 0, or -1 for an invalid transfer set.
+// destination of two transfers and nobody sends to itself (except the one rank of a 1-rank communicator).  Returns 0, or -1 for an
+// invalid transfer set.
 template <class X>
 int transfer(X& x, int me, int n, const int* dst, const double* send, double* recv, int64_t count, double* scratch, int64_t multipath_min_count) {
   if (n < 1 || me < 0 || me >= n || count < 0) return -1;
@@ -38,7 +39,7 @@ int transfer(X& x, int me, int n, const int* dst, const double* send, double* re
   for (int r = 0; r < n; ++r) {
     const int b = dst[r];
     if (b < 0) continue;
-    if (b >= n || b == r || src[(size_t)b] >= 0) return -1;
+    if (b >= n || (b == r && n > 1) || src[(size_t)b] >= 0) return -1;      // (a lone rank may send to itself: one send + one receive through the transport)
     src[(size_t)b] = r;
   }
   if (count == 0) return 0;

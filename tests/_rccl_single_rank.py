@@ -33,6 +33,14 @@ ck(L.capi_allgather(comm, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), n)
 ck(L.capi_sendrecv_replace(comm, C.c_void_p(x.data_ptr()), n, 0, C.c_void_p(stg.data_ptr())), "sendrecv_replace")
 h.sync()
 assert torch.equal(y, ref) and torch.equal(x, ref) and torch.equal(stg, ref)
+# the multi-path transfer wrapper (csrc/pair_paths.h over ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd): the one rank sends to itself
+y.zero_()
+dst = (C.c_int * 1)(0)
+ck(L.capi_pairs_transfer(comm, dst, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), n, None), "pairs_transfer (self, through RCCL)")
+h.sync()
+assert torch.equal(y, ref)
+dst[0] = -1
+ck(L.capi_pairs_transfer(comm, dst, None, None, n, None), "pairs_transfer (nothing to send)")
 child = C.c_void_p()
 ck(L.capi_comm_split(comm, 0, 0, C.byref(child)), "comm_split")
 r, s = C.c_int(-1), C.c_int(-1)

@@ -1447,6 +1447,10 @@ __device__ __forceinline__ void trmm_ts32_body(const GemmArgs& p, double* __rest
       for (int q = 0; q < 8; ++q) { Ln[lofs + 512 * q] = st[q].x; Ln[HALF + lofs + 512 * q] = st[q].y; }
     } else if (tile + dt < ntile) stage(lds + (par ^ 1) * TILE, tile + dt, st);
     par ^= 1;
+    // (The reverse order -- stage, fetch TWO tiles ahead, store, and only then the barrier, so that nothing but the first LDS reads stands
+    //  between the barrier and the MFMAs -- was measured build against build: 5.40 / 5.17 / 5.31 / 5.02 ms against 4.92 / 4.66 / 4.87 / 4.55
+    //  (cm->cm / cm->p32 / p32->cm / p32->p32), CholeskyQR2 19.44 against 19.11 ms: slower, like the LDS-DMA form, which shares the
+    //  two-tile fetch distance.  profiles/r3z_*.)
     __syncthreads();
     // lane holds rows 2 r16, 2 r16 + 1 of columns j = 16 strip + g + 4 reg: one 16-byte store per column, 16 lanes -> the tile's whole
     // 256-byte segment of that column

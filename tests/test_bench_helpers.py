@@ -27,7 +27,7 @@ def test_grid_and_base_case_rule():
 def test_recorded_traffic_reads_the_committed_passes():
     import bench
     t, src = bench.recorded_traffic(65536, 1)
-    assert t is not None and 1e10 < t < 2e11 and "recorded" in src and "r2_pmc" in src
+    assert t is not None and 1e10 < t < 2e11 and "recorded" in src and "r3_pmc" in src and "captured at commit" in src
     t2, _ = bench.recorded_traffic(32768, 1)
     assert t2 is not None and 5e9 < t2 < 5e10
     assert bench.recorded_traffic(65536, 8) == (None, None)

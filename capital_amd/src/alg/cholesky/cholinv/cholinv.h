@@ -374,6 +374,12 @@ private:
     return e ? (int64_t)atoll(e) : (int64_t)2048;
   }
 
+  // how many trailing updates may run beside the recursion at once (CAPITAL_LA_DEPTH, default and maximum LA_MAX_DEPTH = 2 bulk streams)
+  static int lookahead_depth() {
+    const char* e = getenv("CAPITAL_LA_DEPTH");
+    return e ? std::max(0, std::min(atoi(e), (int)LA_MAX_DEPTH)) : (int)LA_MAX_DEPTH;
+  }
+
   // columns [x0,x1), rows [y0,y1) of a full local image into the packed (uppertri) factor; shape = what is copied per column
   template <typename ArgType>
   static void pack_block(ArgType&, int shape, const double* full, double* packed_dst, int64_t ld, int64_t x0, int64_t x1, int64_t y0,
@@ -454,7 +460,7 @@ private:
       }
       const U lead = split2 >> args.split;
       const bool a22_splits = !(((split2 * (U)t.d) <= args.bcDimension) || (lead < args.split));
-      const bool la = single && a22_splits && lead > 0 && lookahead_min() >= 0 && (int64_t)split2 >= lookahead_min() && args.la_depth < LA_MAX_DEPTH;
+      const bool la = single && a22_splits && lead > 0 && lookahead_min() >= 0 && (int64_t)split2 >= lookahead_min() && args.la_depth < lookahead_depth();
       const bool pack_now = top && !std::is_same<typename SP::structure, rect>::value;
       // R12 into R (cholinv.hpp:122).  At the top level with lookahead and packed factors nothing reads it there before the
       // early packing: the copy then goes with the packing, behind the bulk of the update (W stays allocated until the join)

@@ -554,6 +554,12 @@ __global__ void trizero2_kernel(int64_t n, double* __restrict__ A, int64_t lda, 
 //   phase 2  the inverse's off-diagonal blocks level by level (X12 = -X11 R12 X22 at block sizes 128, 256, ...): all pairs
 //            of a level are independent and go out as ONE strided-batch launch per product -- 2 log2(n/128) launches.
 // `W`: scratch of 128 * n + n * n / 4 doubles.
+// (Round 3, measured and removed: one block of lookahead in phase 1 -- the update cut into U1 = the next diagonal block and the rest, the
+//  NEXT leaf on a side stream beside that rest, the panel formed out of place and written back behind the leaf.  Per step the chain is then
+//  panel + U1 + max(rest of the update, leaf) instead of leaf + panel + update, on paper 59 against 95 us.  Parity-green, and slower:
+//  order 1024 509 -> 690 us, 4096 3.11 -> 3.40 ms, the n = 32768 step 234 -> 272 ms.  Two cross-stream hand-offs per 128 columns (event
+//  record on one HIP stream, wait on the other) cost more than the 41 us leaf they hide: a dependency between two hardware queues is
+//  resolved by barrier packets and signal polling, an order of magnitude slower than the next packet of the same queue.  profiles/r4c_*.)
 int potrf_trtri_blocked(capi_handle_t h, int64_t n, double* A, int64_t lda, double* X, int64_t ldx, int info_base, double* W) {
   const int64_t nblk = cdiv(n, (int64_t)LEAF);
   for (int64_t j = 0; j < nblk; ++j) {

@@ -230,7 +230,9 @@ public:
     void wait(int s) { if (on) CAPITAL_CHECK(capi_event_wait(h, base + s)); }
   };
   static int chunk_count(size_t num_chunks, int64_t cols) {
-    static const int64_t min_cols = getenv("CAPITAL_MIN_CHUNK_COLS") ? std::max(2, atoi(getenv("CAPITAL_MIN_CHUNK_COLS"))) : 128;   // tests shrink it
+    // (a chunk costs two cross-stream hand-offs -- event record on one HIP stream, wait on the other: tens of microseconds between two
+    //  hardware queues, measured in round 3 --, so it has to carry work in the 100-microsecond range: 512 columns; tests shrink it)
+    static const int64_t min_cols = getenv("CAPITAL_MIN_CHUNK_COLS") ? std::max(2, atoi(getenv("CAPITAL_MIN_CHUNK_COLS"))) : 512;
     int n = (int)std::min<int64_t>((int64_t)std::min<size_t>(num_chunks, 64), std::max<int64_t>(cols / min_cols, 1));
     return n < 1 ? 1 : n;
   }

@@ -332,9 +332,14 @@ def main():
             name, chunks, mp = cur[:3]
             if best_bc:
                 bc = best_bc[0]
+            plain = (forms[0][0], forms[0][1], forms[0][2], r, bc_mult_for(n, d, c, BASE_CASE_ORDER) if args.bc is None else args.bc)
             r = time_cholesky(driver, L, h, n, c, bc, chunks, args.steps, args.warmup, distributed, device, bc_policy=0, multipath=mp)
             comm_forms.append({"form": name, "chunks": chunks, "multipath": mp, "base_case_order": r["stats"]["bc_dimension"],
                                "ms_per_step": r["ms_per_step"], "residual": r["residual"], "timed": "full"})
+            # the full run of the chosen form must validate and must still be the faster one: else the plain form's measurement stands
+            if max_over_ranks(r["residual"], distributed, device) > 1e-14 or r["ms_per_step"] >= plain[3]["ms_per_step"]:
+                name, chunks, mp, r, bc = plain
+                comm_forms.append({"form": name, "note": "reported: the chosen form's full run did not validate or was not faster"})
         timer.cancel()
     residual_max = max_over_ranks(r["residual"], distributed, device)
     out = make_line(args, n, bc, r, chunks, mp, rccl, residual_max, comm_forms if distributed else None, recorded_traffic(n, args.gpus))

@@ -2044,6 +2044,7 @@ __attribute__((visibility("hidden"))) int capi_internal_trmm_oop_batched(capi_ha
                                                                            int64_t m, int64_t n, double alpha, const double* T,
                                                                            int64_t ldt, int64_t st, const double* B, int64_t ldb,
                                                                            int64_t sb_, double* C, int64_t ldc, int64_t sc_, int batch) {
+  CAPI_REQUIRE(h, h && m >= 0 && n >= 0 && m < (1LL << 31) && n < (1LL << 31) && batch >= 0, "dims");      // (GemmArgs carries 32-bit extents)
   const bool small_ok = m <= 512 && n <= 512 && !getenv("CAPI_SMALL");
   const bool aligned = ((st | sb_ | sc_) & 1) == 0;      // keeps the 16-byte alignment decision valid for every batch member
   if (batch > 1 && small_ok && aligned) {

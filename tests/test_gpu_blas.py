@@ -500,3 +500,44 @@ def test_panel32_entry_points_reject_what_they_cannot_serve(hip):
     assert L.capi_set_launch_rounds(h, 1, C.byref(was)) == 0 and was.value == 0
     assert L.capi_set_launch_rounds(h, 0, C.byref(was)) == 0 and was.value == 1
     assert L.capi_set_launch_rounds(h, 2, None) != 0
+
+
+@pytest.mark.gpu
+def test_launches_in_resident_rounds_give_the_same_products(hip):
+    """capi_set_launch_rounds(1) (what cholinv::factor turns on for grids): plain products and triangular outputs one resident round of 512
+    tiles per launch, TRMMs as equal-work tile pairs one round per launch.  The tiles, their k order and so every sum are those of the
+    one-launch form: dgemm and dsyrk must come out BIT-identical; the pair kernel walks its long tile backwards in k, so the TRMM is held
+    to 1e-13 against the default form and a plain torch product."""
+    import ctypes as C
+    import torch
+    from capital_amd import capi
+    L = capi.load()
+    n = 8192                                                       # 4096 tiles of 128 (8 rounds); triangle 2080 tiles (4 rounds + a re-cut tail); 2048 pair workgroups
+    torch.manual_seed(8192)
+    A = torch.rand((n, n), dtype=torch.float64, device="cuda") - 0.5
+    B = torch.rand((n, n), dtype=torch.float64, device="cuda") - 0.5
+    T = torch.triu(torch.rand((n, n), dtype=torch.float64, device="cuda") - 0.5).T.contiguous()      # column-major upper
+
+    def products():
+        Cg = torch.zeros((n, n), dtype=torch.float64, device="cuda")
+        Cs = torch.zeros((n, n), dtype=torch.float64, device="cuda")
+        Ct = torch.zeros((n, n), dtype=torch.float64, device="cuda")
+        hip.call("capi_dgemm", 1, 0, n, n, n, 1.0, capi.ptr(A), n, capi.ptr(B), n, 0.0, capi.ptr(Cg), n)
+        hip.call("capi_dsyrk", 1, 1, n, n, -1.0, capi.ptr(A), n, 0.0, capi.ptr(Cs), n)
+        hip.call("capi_dtrmm_oop", 0, 1, 1, 0, n, n, 1.0, capi.ptr(T), n, capi.ptr(B), n, capi.ptr(Ct), n)
+        hip.sync()
+        return Cg, Cs, Ct
+
+    base = products()
+    was = C.c_int(-1)
+    assert L.capi_set_launch_rounds(hip.h, 1, C.byref(was)) == 0
+    try:
+        rounds = products()
+    finally:
+        assert L.capi_set_launch_rounds(hip.h, 0, None) == 0
+    assert torch.equal(base[0], rounds[0])
+    assert torch.equal(base[1], rounds[1])
+    scale = base[2].abs().max().item()
+    assert (base[2] - rounds[2]).abs().max().item() <= 1e-13 * scale
+    ref = (torch.triu(T.T).T @ B.T).T                               # column-major: Ct = T^T B
+    assert (rounds[2] - ref).abs().max().item() <= 1e-12 * scale

@@ -57,6 +57,7 @@ _SIGS = {
     "capi_mfma_f64_peak": [_int, C.POINTER(_dbl)],
     "capi_prof_enable": [_int],
     "capi_prof_collect": [_int, C.POINTER(_i64), C.POINTER(_dbl), C.POINTER(_dbl), C.POINTER(_dbl)],
+    "capi_prof_collect_intervals": [_int, C.POINTER(_i64), C.POINTER(_dbl), C.POINTER(_dbl), C.POINTER(_dbl), C.POINTER(_dbl)],
     "capi_stream_select": [_int],
     "capi_event_record": [_int],
     "capi_event_wait": [_int],

@@ -92,6 +92,7 @@ int capi_destroy(capi_handle_t h) {
   if (h->h_info) (void)hipHostFree(h->h_info);
   for (int i = 0; i < h->prof_cap; ++i) if (h->prof[i].e0) { (void)hipEventDestroy(h->prof[i].e0); (void)hipEventDestroy(h->prof[i].e1); }
   free(h->prof);
+  if (h->d_stamps) (void)hipFree(h->d_stamps);
   for (int i = 0; i < h->graphs_n; ++i) if (h->graphs[i].exec) (void)hipGraphExecDestroy(h->graphs[i].exec);
   free(h->graphs);
   if (h->ev0) (void)hipEventDestroy(h->ev0);

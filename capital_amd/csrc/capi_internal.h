@@ -41,6 +41,10 @@ struct capi_handle_s {
   struct prof_rec { hipEvent_t e0, e1; double flops; int variant; int m, n, k, kind; };   // kind: 0 plain, 1 triangular output, 2 TRMM
   prof_rec* prof = nullptr;
   int prof_n = 0, prof_cap = 0;
+  // per-launch execution intervals written by the tile kernels themselves (gemm_f64.hip: stamp_begin / stamp_end), record i at [2 i, 2 i + 1]
+  unsigned long long* d_stamps = nullptr;
+  int stamps_cap = 0;
+  int wall_khz = 100000;          // rate of wall_clock64() (hipDeviceAttributeWallClockRate)
   // kernels whose dynamic-LDS limit has been raised on THIS handle's device (hipFuncSetAttribute is per device; a
   // process-wide flag would leave a second device's copy of the kernel at the default limit)
   uint32_t lds_attr_done = 0;

@@ -98,7 +98,19 @@ struct GemmArgs {
   int order;          // bit 0: a triangular output's tiles run in bands of 8 tile rows (tile_of_dims)
   int a_tiled, c_tiled;   // tall-skinny kernels (n == 256): the tall operand / the output is a "panel32" image -- tiles of 32 rows x 256 columns,
                       // each column-major with ld 32, tile t at 32 * 256 * t: every pass over the panel is ONE contiguous stream
+  unsigned long long* stamp;   // capi_prof_*: this launch's record {min over workgroups of the start time, min of ~(end time)} in 100 MHz wall-clock
+                               // ticks, both initialised to ~0 -- the launch's EXECUTION interval, whatever else shares the device with it
 };
+
+// One atomic per workgroup at either end (512 per resident round): the interval in which the launch really had workgroups on the device.
+// HIP events around a launch are stream-ordered: with launches of several streams interleaved round by round, an event bracket also
+// contains the neighbours' rounds (round 3: the brackets summed to 1.11 x the step) -- these stamps do not.
+__device__ __forceinline__ void stamp_begin(const GemmArgs& p) {
+  if (p.stamp && threadIdx.x == 0) atomicMin(p.stamp, (unsigned long long)wall_clock64());
+}
+__device__ __forceinline__ void stamp_end(const GemmArgs& p) {
+  if (p.stamp && threadIdx.x == 0) atomicMin(p.stamp + 1, ~(unsigned long long)wall_clock64());
+}
 
 // ---- global -> registers: this thread's 4 x 16 bytes of a 128 x 16 operand panel -----------------
 template <int TS, bool KC>
@@ -322,6 +334,7 @@ __global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel
   const int lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, g = lane >> 4;
   const int wm = wave & 1, wn = wave >> 1;
+  stamp_begin(p);
 
   // XCD-aware re-deal: consecutive pids share an XCD (dispatcher deals blockIdx round-robin over 8 XCDs)
   const int nblk = gridDim.x, bid = blockIdx.x;
@@ -595,6 +608,7 @@ __global__ __launch_bounds__(NTHREADS, TS == 128 ? 2 : 4) void dgemm_tile_kernel
         }
     }
   }
+  stamp_end(p);
 }
 
 // ---- TRMM in tile PAIRS ------------------------------------------------------------------------------------------
@@ -620,6 +634,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void dtrmm_pair_kernel(const GemmArgs 
   const int lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, g = lane >> 4;
   const int wm = wave & 1, wn = wave >> 1;
+  stamp_begin(p);
 
   const int nblk = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, qq = nblk >> 3, rr = nblk & 7;
@@ -792,6 +807,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void dtrmm_pair_kernel(const GemmArgs 
         }
     }
   }
+  stamp_end(p);
 }
 
 // C(part) <- alpha * sum_z slab[z] + beta*C   (fixed summation order: bit-reproducible)
@@ -1803,6 +1819,11 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
     CAPI_HIP_CHECK(h, hipEventRecord(rec->e0, s));
     return CAPI_OK;
   };
+  // the launch's device-side interval record (capi_prof_collect_intervals), or null when profiling is off / the pool is exhausted
+  auto stamp_of = [&](const capi_handle_s::prof_rec* rec) -> unsigned long long* {
+    const int64_t idx = rec ? rec - h->prof : -1;
+    return (rec && h->d_stamps && idx < h->stamps_cap) ? h->d_stamps + 2 * idx : nullptr;
+  };
   // Resident rounds (plain products).  A launch with more tiles than the chip holds (2 per CU) refills slots one by one as tiles
   // finish: within a few tile lengths the starts are smeared and tiles that share an operand panel are no longer within the ~2
   // iterations an XCD's 4 MiB L2 can bridge (its 64 resident tiles pull 2 MiB of panels through it per iteration).  One launch per
@@ -1843,6 +1864,7 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
           int rc = prof_open((double)per_round / (double)wgs, rec);
           if (rc != CAPI_OK) return rc;
           if (rec) rec->variant += 16;
+          q.stamp = stamp_of(rec);
           hipLaunchKernelGGL(kp, dim3((unsigned)per_round), dim3(NTHREADS), lds_bytes, s, q);
           if (rec) CAPI_HIP_CHECK(h, hipEventRecord(rec->e1, s));
         }
@@ -1853,6 +1875,7 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
       int rc = prof_open(1.0, rec);
       if (rc != CAPI_OK) return rc;
       if (rec) rec->variant += 16;                                      // its own kernel symbol: not counted with dgemm_tile_kernel's launches
+      p.stamp = stamp_of(rec);
       hipLaunchKernelGGL(kp, dim3((unsigned)wgs), dim3(NTHREADS), lds_bytes, s, p);
       if (rec) CAPI_HIP_CHECK(h, hipEventRecord(rec->e1, s));
       CAPI_HIP_CHECK(h, hipGetLastError());
@@ -1867,6 +1890,7 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
       capi_handle_s::prof_rec* rec;
       int rc = prof_open((double)cnt / (double)ntiles_all, rec);
       if (rc != CAPI_OK) return rc;
+      q.stamp = stamp_of(rec);
       hipLaunchKernelGGL(k, dim3((unsigned)cnt), dim3(NTHREADS), lds_bytes, s, q);
       if (rec) CAPI_HIP_CHECK(h, hipEventRecord(rec->e1, s));
     }
@@ -1874,6 +1898,7 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
     capi_handle_s::prof_rec* rec;
     int rc = prof_open((double)p.ntiles / (double)ntiles_all, rec);              // (the tail launch below is not part of this record)
     if (rc != CAPI_OK) return rc;
+    p.stamp = stamp_of(rec);
     hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(NTHREADS), lds_bytes, s, p);
     if (rec) CAPI_HIP_CHECK(h, hipEventRecord(rec->e1, s));
   }
@@ -1881,6 +1906,7 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
   if (tail128 > 0) {
     GemmArgs q = p;
     q.ts = 64;
+    q.stamp = nullptr;                      // (the tail is neither in the record's flops nor in its interval)
     q.tail_base = p.ntiles;                 // first 128-tile of the tail (p.ntiles > 0 here)
     q.tail_tm = p.tiles_m; q.tail_tn = p.tiles_n;
     q.tiles_m = (int)cdiv(p.M, 64); q.tiles_n = (int)cdiv(p.N, 64);
@@ -2126,7 +2152,68 @@ int capi_dtrmm_right_panel32(capi_handle_t h, int64_t m, int64_t n, double alpha
 int capi_prof_enable(capi_handle_t h, int on) {
   CAPI_REQUIRE(h, h, "null handle");
   h->prof_on = on != 0;
-  if (on) h->prof_n = 0;
+  if (on) {
+    h->prof_n = 0;
+    // device-side interval records, two 64-bit words per launch, all ones = "no workgroup has reported yet" (see stamp_begin / stamp_end)
+    if (!h->d_stamps) {
+      CAPI_HIP_CHECK(h, hipSetDevice(h->device));
+      h->stamps_cap = 1 << 16;
+      CAPI_HIP_CHECK(h, hipMalloc((void**)&h->d_stamps, sizeof(unsigned long long) * 2 * (size_t)h->stamps_cap));
+      int khz = 0;
+      if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->device) == hipSuccess && khz > 0) h->wall_khz = khz;
+    }
+    CAPI_HIP_CHECK(h, hipMemsetAsync(h->d_stamps, 0xff, sizeof(unsigned long long) * 2 * (size_t)h->stamps_cap, h->stream));
+    CAPI_HIP_CHECK(h, hipStreamSynchronize(h->stream));        // launches of the handle's other streams must find the records initialised
+  }
+  return CAPI_OK;
+}
+
+// The same records as capi_prof_collect, timed by the kernels themselves: every recorded launch carries the interval [first workgroup's
+// start, last workgroup's end] in wall-clock ticks.  *union_ms = the length of the UNION of those intervals (time during which at least
+// one of the selected launches had workgroups on the device), *sum_ms their sum, *max_ms the longest.  Achieved rate of a kernel in a step
+// whose launches interleave across streams = total_flops / union_ms; stream-ordered event brackets (capi_prof_collect) overstate the
+// durations there, because a bracket also contains the rounds of other streams that ran between its two events.
+int capi_prof_collect_intervals(capi_handle_t h, int variant, int64_t* launches, double* union_ms, double* sum_ms, double* total_flops, double* max_ms) {
+  CAPI_REQUIRE(h, h && launches && union_ms && sum_ms && total_flops, "args");
+  *launches = 0; *union_ms = 0; *sum_ms = 0; *total_flops = 0;
+  if (max_ms) *max_ms = 0;
+  if (!h->d_stamps || h->prof_n == 0) return CAPI_OK;
+  CAPI_HIP_CHECK(h, hipSetDevice(h->device));
+  int rc = capi_sync(h);
+  if (rc != CAPI_OK) return rc;
+  const int n = h->prof_n < h->stamps_cap ? h->prof_n : h->stamps_cap;
+  unsigned long long* st = (unsigned long long*)malloc(sizeof(unsigned long long) * 2 * (size_t)n);
+  if (!st) return CAPI_ENOMEM;
+  hipError_t e = hipMemcpy(st, h->d_stamps, sizeof(unsigned long long) * 2 * (size_t)n, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) { free(st); CAPI_HIP_CHECK(h, e); }
+  struct iv { unsigned long long a, b; };
+  iv* v = (iv*)malloc(sizeof(iv) * (size_t)n);
+  if (!v) { free(st); return CAPI_ENOMEM; }
+  int m = 0;
+  const double ms_per_tick = 1.0 / (double)h->wall_khz;
+  static const bool dump = getenv("CAPI_PROF_DUMP") != nullptr;
+  for (int i = 0; i < n; ++i) {
+    if (variant >= 8 ? h->prof[i].variant != variant - 8 : (variant >= 0 && (h->prof[i].variant & 3) != variant)) continue;
+    const unsigned long long a = st[2 * i], b = ~st[2 * i + 1];
+    if (st[2 * i] == ~0ull || st[2 * i + 1] == ~0ull || b < a) continue;       // (a launch without workgroups, or not yet run)
+    v[m++] = {a, b};
+    const double ms = (double)(b - a) * ms_per_tick;
+    *launches += 1; *sum_ms += ms; *total_flops += h->prof[i].flops;
+    if (max_ms && ms > *max_ms) *max_ms = ms;
+    if (dump && variant < 0)
+      fprintf(stderr, "[capi prof iv] %4d %s v%d M=%d N=%d K=%d  start %.3f ms  %9.3f ms  %6.2f TF/s\n", i, h->prof[i].kind == 0 ? "gemm" : h->prof[i].kind == 1 ? "syrk" : "trmm",
+              h->prof[i].variant, h->prof[i].m, h->prof[i].n, h->prof[i].k, (double)(a - st[0]) * ms_per_tick, ms, h->prof[i].flops / ms * 1e-9);
+  }
+  // union of the intervals: sort by start, merge
+  for (int i = 1; i < m; ++i) { iv x = v[i]; int j = i - 1; while (j >= 0 && v[j].a > x.a) { v[j + 1] = v[j]; --j; } v[j + 1] = x; }   // (nearly sorted already)
+  unsigned long long covered = 0, cur_a = 0, cur_b = 0;
+  for (int i = 0; i < m; ++i) {
+    if (i == 0 || v[i].a > cur_b) { covered += cur_b - cur_a; cur_a = v[i].a; cur_b = v[i].b; }
+    else if (v[i].b > cur_b) cur_b = v[i].b;
+  }
+  covered += cur_b - cur_a;
+  *union_ms = (double)covered * ms_per_tick;
+  free(v); free(st);
   return CAPI_OK;
 }
 

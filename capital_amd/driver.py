@@ -14,7 +14,7 @@ import torch
 from . import capi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-DRV_PATH = os.path.join(_HERE, "libcapital_driver.so")
+DRV_PATH = os.environ.get("CAPITAL_DRIVER_LIB", os.path.join(_HERE, "libcapital_driver.so"))   # override: A/B builds of the same ABI
 _i64, _dbl, _int, _vp = C.c_int64, C.c_double, C.c_int, C.c_void_p
 _dp = C.POINTER(C.c_double)
 _drv = None

@@ -148,10 +148,11 @@ public:
     // the reference's simulate() (cholinv.hpp:50-83) pre-allocates every level's tables; here ONE arena covers the
     // deepest concurrent need: panels + partial sums of the top level, or the aggregated base case
     const bool single = (CommInfo.d == 1 && CommInfo.c == 1);
-    // grids: every product runs on the compute stream, so the large launches go out one resident round at a time -- same time, half the
-    // L2-to-fabric traffic (bandwidth the collectives' copy kernels share); on one GPU the rounds of the lookahead's bulk streams would
-    // interleave
-    capital::launch_rounds_scope rounds(!single);
+    // the large launches go out one resident round at a time: same time, half the L2-to-fabric traffic (on grids: bandwidth the collectives'
+    // copy kernels share).  On one GPU the rounds of the lookahead's bulk streams interleave with each other and with the chain -- harmless,
+    // but stream-ordered event brackets around a round then also contain its neighbours, which is why the roofline figure is taken from the
+    // kernels' own interval stamps (capi_prof_collect_intervals).  CAPITAL_NO_LAUNCH_ROUNDS: one launch per product.
+    capital::launch_rounds_scope rounds(true);
     const U h = localDimension - (localDimension >> args.split);
     const U agg = args.bcDimension;
     // (single GPU: the R12 copies of nested levels stay live while their trailing updates run beside the recursion: h^2 (1 + 1/4 + ...))

@@ -217,6 +217,9 @@ int capi_mfma_f64_peak(capi_handle_t h, int iters, double* tflops);
  * alone, i.e. one kernel symbol; -1 = all variants). */
 int capi_prof_enable(capi_handle_t h, int on);
 int capi_prof_collect(capi_handle_t h, int variant, int64_t* launches, double* total_ms, double* total_flops, double* max_ms);
+/* the same records timed by the kernels themselves (first workgroup's start .. last workgroup's end, wall-clock ticks): *union_ms = length
+ * of the union of the selected launches' execution intervals, *sum_ms their sum.  Robust to launches of several streams interleaving. */
+int capi_prof_collect_intervals(capi_handle_t h, int variant, int64_t* launches, double* union_ms, double* sum_ms, double* total_flops, double* max_ms);
 /* phase markers: the reference's CRITTER_START/STOP(sym) regions (src/util/shared.h:26-35; cholinv.hpp:94-158, cacqr.hpp:82-116)
  * as roctx ranges for `rocprofv3 --marker-trace`; no-ops when no roctx library can be bound */
 int capi_range_push(const char* name);

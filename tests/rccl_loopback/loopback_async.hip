@@ -1,0 +1,359 @@
+// loopback_async.hip -- TEST INFRASTRUCTURE (never loaded by the product on its own): the ASYNCHRONOUS mode of the loopback transport.
+//
+// The host-staged mode (rccl_loopback.cpp) drains the caller's stream around every message, so every call has completed when it returns:
+// a legal execution of RCCL's API, and one on which a missing consumer-side wait in the product's chunk pipelines cannot fail.  This
+// mode behaves like RCCL does: a call ENQUEUES device work on the caller's stream and returns; nothing here calls hipStreamSynchronize,
+// waits for an event on the host, or looks at data.  What the reference gets from MPI_Ibcast / MPI_Iallreduce + MPI_Wait
+// (summa.hpp:195-215,238-249) -- transfers that progress beside the local BLAS call -- is then really asynchronous in the rehearsal too.
+//
+// All ranks sit on ONE GPU in separate processes (ipc_probe.cpp established what the pool's driver offers two such processes):
+//   * every ordered pair (src, dst) of a communicator has a CHANNEL: a ring of device memory that src allocates and exports
+//     (hipIpcGetMemHandle) and dst maps (hipIpcOpenMemHandle), plus two counters in a host page both registered with HIP;
+//   * send  = [wait until the ring region is free again: hipStreamWaitValue32 on `consumed`] -> copy kernel user buffer -> ring ->
+//             hipStreamWriteValue32(posted = seq), all on the caller's stream;
+//   * recv  = hipStreamWaitValue32(posted >= seq) -> copy (or add) kernel ring -> user buffer -> hipStreamWriteValue32(consumed = seq);
+//   * the copy kernels run with a configurable number of workgroups (CAPI_LOOPBACK_COPY_WGS, default 16) -- like RCCL's point-to-point
+//     kernels they occupy CUs beside the caller's compute kernels -- and an optional delay in front of every receive-side copy
+//     (CAPI_LOOPBACK_DELAY_US) widens the window in which a consumer that did not wait reads stale bytes.
+// Both sides of a channel place messages in the ring with the same deterministic rule (sizes match on both sides, as NCCL demands), so
+// no descriptor travels; the host only meets its peer when a ring is first created or has to grow (the sender publishes a new
+// generation, the receiver maps it).  A ring holds at least four messages of the largest size seen, so a sender only ever waits for
+// the consumption of messages at least three back: inside one ncclGroup at most three messages per (communicator, peer, direction).
+// A watchdog thread ends the process with a diagnosis when device-side waits stop making progress (CAPI_LOOPBACK_TIMEOUT_S).
+#include "loopback_async.h"
+
+#include <atomic>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <fcntl.h>
+#include <mutex>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <thread>
+#include <unistd.h>
+#include <vector>
+
+namespace lb_async {
+namespace {
+
+constexpr int MAX_GEN = 24;
+struct alignas(256) Channel {
+  uint32_t posted;            // device-written: messages whose bytes are in the ring
+  uint32_t consumed;          // device-written: messages the receiver has copied out
+  uint32_t gen;               // host-written by the sender (release): generation of the ring it has published
+  uint32_t pad_;
+  uint64_t capacity;          // bytes of that generation
+  hipIpcMemHandle_t handle[MAX_GEN];   // one per generation (a ring at least doubles when it grows: 1 MiB .. 2^(20 + MAX_GEN) bytes), so a receiver
+                                       // that lags its sender by several growths still maps the generation its message sits in
+};
+struct alignas(256) Header {
+  uint32_t magic, size, bar_count, bar_gen;
+};
+constexpr uint32_t MAGIC = 0x4c424153u;
+
+struct Msg { uint32_t seq; size_t off, end; };
+struct Ring {                  // one direction of one channel, as THIS side sees it
+  uint32_t gen = 0, seq = 0;
+  size_t capacity = 0, head = 0;
+  char* base = nullptr;        // sender: its own allocation; receiver: the mapping
+  std::deque<Msg> live;
+  std::vector<char*> retired;  // earlier generations: released at detach (messages may still be in flight in them)
+};
+
+double timeout_s() {
+  const char* e = getenv("CAPI_LOOPBACK_TIMEOUT_S");
+  return e ? atof(e) : 120.0;
+}
+int copy_wgs() {
+  static const int v = [] { const char* e = getenv("CAPI_LOOPBACK_COPY_WGS"); int w = e ? atoi(e) : 16; return w < 1 ? 1 : (w > 1024 ? 1024 : w); }();
+  return v;
+}
+long delay_us() {
+  static const long v = [] { const char* e = getenv("CAPI_LOOPBACK_DELAY_US"); long d = e ? atol(e) : 0; return d < 0 ? 0 : (d > 1000000 ? 1000000 : d); }();
+  return v;
+}
+
+// The placement rule both sides run.  Returns the offset of the message and, through wait_seq, the newest earlier message whose region it
+// overlaps (0: none) -- the sender must not write before that one has been consumed.  grew: a new generation starts with this message.
+size_t ring_place(Ring& r, size_t bytes, uint32_t& wait_seq, bool& grew) {
+  const size_t need = (bytes + 255) & ~(size_t)255;
+  grew = false;
+  wait_seq = 0;
+  if (4 * need > r.capacity || r.gen == 0) {
+    size_t cap = (size_t)1 << 20;
+    while (cap < 4 * need) cap <<= 1;
+    if (cap < r.capacity) cap = r.capacity;
+    r.capacity = cap;
+    r.head = 0;
+    r.live.clear();
+    ++r.gen;
+    grew = true;
+  }
+  if (r.head + need > r.capacity) r.head = 0;
+  const size_t off = r.head, end = off + need;
+  while (!r.live.empty() && r.live.front().off < end && r.live.front().end > off) {      // the oldest messages are the ones in the way
+    wait_seq = r.live.front().seq;
+    r.live.pop_front();
+  }
+  ++r.seq;
+  r.live.push_back({r.seq, off, end});
+  r.head = end;
+  return off;
+}
+
+__global__ void lb_copy_kernel(char* __restrict__ dst, const char* __restrict__ src, size_t bytes, int accumulate) {
+  const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, nthr = (size_t)gridDim.x * blockDim.x;
+  const bool al16 = ((((uintptr_t)dst) | ((uintptr_t)src)) & 15) == 0;
+  if (accumulate) {                                   // doubles (the reductions' only type here)
+    double* d = (double*)dst;
+    const double* s = (const double*)src;
+    for (size_t i = tid; i < bytes / 8; i += nthr) d[i] = d[i] + s[i];
+    return;
+  }
+  size_t done = 0;
+  if (al16) {
+    const size_t n16 = bytes / 16;
+    uint4* d = (uint4*)dst;
+    const uint4* s = (const uint4*)src;
+    for (size_t i = tid; i < n16; i += nthr) d[i] = s[i];
+    done = n16 * 16;
+  }
+  for (size_t i = done + tid; i < bytes; i += nthr) dst[i] = src[i];
+}
+// a bounded wait (the wall clock runs at 100 MHz): leaves on its own, whatever happens elsewhere
+__global__ void lb_delay_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+
+struct Registry;
+Registry& registry();
+
+}  // namespace
+
+struct AComm {
+  std::string path;
+  int rank = 0, size = 1;
+  size_t map_bytes = 0;
+  char* map = nullptr;          // host view of the control segment
+  char* map_dev = nullptr;      // its device alias (hipHostGetDevicePointer)
+  bool registered = false;
+  std::vector<Ring> tx, rx;     // per peer
+  void* scr = nullptr;
+  size_t scr_bytes = 0;
+  std::mutex mu;
+  Header* hdr() const { return (Header*)map; }
+  Channel* ch(int src, int dst) const { return (Channel*)(map + sizeof(Header)) + (size_t)src * size + dst; }
+  template <typename T> T* dev(T* host_ptr) const { return (T*)(map_dev + ((char*)host_ptr - map)); }
+};
+
+namespace {
+
+struct Registry {
+  std::mutex mu;
+  std::vector<AComm*> comms;
+  bool started = false;
+  void watch() {
+    uint64_t last = ~0ull;
+    auto since = std::chrono::steady_clock::now();
+    for (;;) {
+      std::this_thread::sleep_for(std::chrono::milliseconds(500));
+      uint64_t sum = 0;
+      bool outstanding = false;
+      char what[512] = {0};
+      {
+        std::lock_guard<std::mutex> g(mu);
+        for (AComm* c : comms) {
+          std::lock_guard<std::mutex> gc(c->mu);
+          for (int p = 0; p < c->size; ++p) {
+            if (p == c->rank) continue;
+            const uint32_t posted = __atomic_load_n(&c->ch(p, c->rank)->posted, __ATOMIC_RELAXED), mine = __atomic_load_n(&c->ch(c->rank, p)->posted, __ATOMIC_RELAXED);
+            const uint32_t consumed = __atomic_load_n(&c->ch(c->rank, p)->consumed, __ATOMIC_RELAXED);
+            sum += (uint64_t)posted + mine + consumed;
+            if (c->rx[p].seq > posted || c->tx[p].seq > mine) {
+              if (!outstanding)
+                snprintf(what, sizeof(what), "%s rank %d <-> %d: receives issued %u, peer posted %u; sends issued %u, posted %u, peer consumed %u", c->path.c_str(),
+                         c->rank, p, c->rx[p].seq, posted, c->tx[p].seq, mine, consumed);
+              outstanding = true;
+            }
+          }
+        }
+      }
+      const auto now = std::chrono::steady_clock::now();
+      if (!outstanding || sum != last) { last = sum; since = now; continue; }
+      if (std::chrono::duration<double>(now - since).count() > timeout_s()) {
+        fprintf(stderr, "rccl_loopback (async): no device-side progress for %.0f s -- %s\n", timeout_s(), what);
+        fflush(stderr);
+        _exit(86);
+      }
+    }
+  }
+};
+Registry& registry() { static Registry* r = new Registry(); return *r; }
+
+bool host_barrier(AComm* c) {
+  Header* h = c->hdr();
+  const uint32_t g = __atomic_load_n(&h->bar_gen, __ATOMIC_ACQUIRE);
+  if (__atomic_add_fetch(&h->bar_count, 1, __ATOMIC_ACQ_REL) == (uint32_t)c->size) {
+    __atomic_store_n(&h->bar_count, 0, __ATOMIC_RELEASE);
+    __atomic_add_fetch(&h->bar_gen, 1, __ATOMIC_ACQ_REL);
+    return true;
+  }
+  const auto t_end = std::chrono::steady_clock::now() + std::chrono::duration<double>(timeout_s());
+  while (__atomic_load_n(&h->bar_gen, __ATOMIC_ACQUIRE) == g) {
+    if (std::chrono::steady_clock::now() > t_end) { fprintf(stderr, "rccl_loopback (async): rank %d of %s waited too long at a barrier\n", c->rank, c->path.c_str()); return false; }
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+  return true;
+}
+
+#define LB_HIP(call)                                                                                                             \
+  do {                                                                                                                           \
+    hipError_t e__ = (call);                                                                                                     \
+    if (e__ != hipSuccess) { fprintf(stderr, "rccl_loopback (async): %s:%d %s -> %s\n", __FILE__, __LINE__, #call, hipGetErrorString(e__)); return false; } \
+  } while (0)
+
+bool launch_copy(void* dst, const void* src, size_t bytes, hipStream_t s, bool accumulate) {
+  if (bytes == 0) return true;
+  hipLaunchKernelGGL(lb_copy_kernel, dim3((unsigned)copy_wgs()), dim3(256), 0, s, (char*)dst, (const char*)src, bytes, accumulate ? 1 : 0);
+  LB_HIP(hipGetLastError());
+  return true;
+}
+
+}  // namespace
+
+AComm* attach(const std::string& dir, const std::string& name, int rank, int size) {
+  AComm* c = new AComm();
+  c->path = dir + "/" + name + ".ctl";
+  c->rank = rank;
+  c->size = size;
+  c->map_bytes = sizeof(Header) + sizeof(Channel) * (size_t)size * size;
+  c->tx.resize(size);
+  c->rx.resize(size);
+  auto fail = [&](const char* what) { fprintf(stderr, "rccl_loopback (async): %s: %s\n", c->path.c_str(), what); delete c; return (AComm*)nullptr; };
+  int fd = -1;
+  if (rank == 0) {
+    const std::string tmp = c->path + ".tmp";
+    fd = open(tmp.c_str(), O_CREAT | O_RDWR | O_TRUNC, 0600);
+    if (fd < 0 || ftruncate(fd, (off_t)c->map_bytes) != 0) return fail("cannot create the control segment");
+    Header h0{MAGIC, (uint32_t)size, 0, 0};
+    if (pwrite(fd, &h0, sizeof(h0), 0) != (ssize_t)sizeof(h0) || rename(tmp.c_str(), c->path.c_str()) != 0) { close(fd); return fail("cannot publish the control segment"); }
+  } else {
+    const auto t_end = std::chrono::steady_clock::now() + std::chrono::duration<double>(timeout_s());
+    while ((fd = open(c->path.c_str(), O_RDWR)) < 0) {
+      if (std::chrono::steady_clock::now() > t_end) return fail("the control segment never appeared");
+      std::this_thread::sleep_for(std::chrono::microseconds(100));
+    }
+  }
+  c->map = (char*)mmap(nullptr, c->map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (c->map == MAP_FAILED) { c->map = nullptr; return fail("mmap failed"); }
+  if (c->hdr()->magic != MAGIC || c->hdr()->size != (uint32_t)size) return fail("control segment of another communicator");
+  if (hipHostRegister(c->map, c->map_bytes, hipHostRegisterMapped) != hipSuccess || hipHostGetDevicePointer((void**)&c->map_dev, c->map, 0) != hipSuccess)
+    return fail("hipHostRegister of the control segment failed");
+  c->registered = true;
+  if (!host_barrier(c)) return fail("peers missing");            // everybody has the page registered before the first counter is written
+  if (rank == 0) unlink(c->path.c_str());                           // the mappings keep it alive; nothing is left behind in /dev/shm
+  Registry& R = registry();
+  std::lock_guard<std::mutex> g(R.mu);
+  R.comms.push_back(c);
+  if (!R.started) { R.started = true; std::thread([&R] { R.watch(); }).detach(); }
+  return c;
+}
+
+void detach(AComm* c) {
+  if (!c) return;
+  {
+    Registry& R = registry();
+    std::lock_guard<std::mutex> g(R.mu);
+    for (size_t i = 0; i < R.comms.size(); ++i) if (R.comms[i] == c) { R.comms.erase(R.comms.begin() + i); break; }
+  }
+  (void)hipDeviceSynchronize();                                      // (ncclCommDestroy is a synchronising call in RCCL too)
+  const bool met = host_barrier(c);                                  // every rank's transfers have completed
+  for (Ring& r : c->rx) {
+    if (r.base) (void)hipIpcCloseMemHandle(r.base);
+    for (char* p : r.retired) (void)hipIpcCloseMemHandle(p);
+  }
+  if (met) (void)host_barrier(c);                                    // every mapping is closed before its owner frees it
+  for (Ring& r : c->tx) {
+    if (r.base) (void)hipFree(r.base);
+    for (char* p : r.retired) (void)hipFree(p);
+  }
+  if (c->scr) (void)hipFree(c->scr);
+  if (c->registered) (void)hipHostUnregister(c->map);
+  if (c->map) munmap(c->map, c->map_bytes);
+  delete c;
+}
+
+void* scratch(AComm* c, size_t bytes) {
+  if (bytes > c->scr_bytes) {
+    // the old block may still be read by work in flight: it is only released once the device has drained (rare: sizes repeat)
+    if (c->scr) { (void)hipDeviceSynchronize(); (void)hipFree(c->scr); c->scr = nullptr; c->scr_bytes = 0; }
+    size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+    if (hipMalloc(&c->scr, want) != hipSuccess) return nullptr;
+    c->scr_bytes = want;
+  }
+  return c->scr;
+}
+
+bool local_copy(void* dst, const void* src, size_t bytes, hipStream_t s, bool accumulate) {
+  if (dst == src && !accumulate) return true;
+  return launch_copy(dst, src, bytes, s, accumulate);
+}
+
+bool send(AComm* c, int peer, const void* buf, size_t bytes, hipStream_t s) {
+  std::lock_guard<std::mutex> g(c->mu);
+  Ring& r = c->tx[peer];
+  Channel* ch = c->ch(c->rank, peer);
+  uint32_t wait_seq = 0;
+  bool grew = false;
+  const size_t off = ring_place(r, bytes, wait_seq, grew);
+  if (grew) {
+    if (r.base) r.retired.push_back(r.base);
+    r.base = nullptr;
+    LB_HIP(hipMalloc((void**)&r.base, r.capacity));
+    if (r.gen >= (uint32_t)MAX_GEN) { fprintf(stderr, "rccl_loopback (async): ring generations exhausted\n"); return false; }
+    LB_HIP(hipIpcGetMemHandle(&ch->handle[r.gen], r.base));
+    ch->capacity = r.capacity;
+    __atomic_store_n(&ch->gen, r.gen, __ATOMIC_RELEASE);
+  }
+  if (wait_seq) LB_HIP(hipStreamWaitValue32(s, c->dev(&ch->consumed), wait_seq, hipStreamWaitValueGte, 0xffffffffu));
+  if (!launch_copy(r.base + off, buf, bytes, s, false)) return false;
+  LB_HIP(hipStreamWriteValue32(s, c->dev(&ch->posted), r.seq, 0));
+  return true;
+}
+
+bool recv(AComm* c, int peer, void* buf, size_t bytes, hipStream_t s, bool accumulate) {
+  std::unique_lock<std::mutex> g(c->mu);
+  Ring& r = c->rx[peer];
+  Channel* ch = c->ch(peer, c->rank);
+  uint32_t wait_seq = 0;
+  bool grew = false;
+  const size_t off = ring_place(r, bytes, wait_seq, grew);
+  const uint32_t seq = r.seq, gen = r.gen;
+  if (grew) {
+    // the one place where a host meets its peer's HOST: the sender has to have published this generation of the ring
+    g.unlock();
+    const auto t_end = std::chrono::steady_clock::now() + std::chrono::duration<double>(timeout_s());
+    while (__atomic_load_n(&ch->gen, __ATOMIC_ACQUIRE) < gen) {
+      if (std::chrono::steady_clock::now() > t_end) { fprintf(stderr, "rccl_loopback (async): rank %d of %s: peer %d never published ring generation %u\n", c->rank, c->path.c_str(), peer, gen); return false; }
+      std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
+    g.lock();
+    if (r.base) r.retired.push_back(r.base);
+    r.base = nullptr;
+    if (gen >= (uint32_t)MAX_GEN) return false;
+    LB_HIP(hipIpcOpenMemHandle((void**)&r.base, ch->handle[gen], hipIpcMemLazyEnablePeerAccess));
+  }
+  LB_HIP(hipStreamWaitValue32(s, c->dev(&ch->posted), seq, hipStreamWaitValueGte, 0xffffffffu));
+  if (delay_us() > 0) { hipLaunchKernelGGL(lb_delay_kernel, dim3(1), dim3(1), 0, s, (long long)delay_us() * 100); LB_HIP(hipGetLastError()); }
+  if (!launch_copy(buf, r.base + off, bytes, s, accumulate)) return false;
+  LB_HIP(hipStreamWriteValue32(s, c->dev(&ch->consumed), seq, 0));
+  return true;
+}
+
+}  // namespace lb_async

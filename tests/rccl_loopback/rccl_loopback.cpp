@@ -11,6 +11,10 @@
 // execution of the asynchronous API for any program whose per-communicator call order agrees across ranks (the same
 // condition RCCL itself imposes).  A wait that exceeds CAPI_LOOPBACK_TIMEOUT_S (default 120) returns ncclSystemError.
 //
+// CAPI_LOOPBACK_MODE=async selects the second transport (loopback_async.hip): the same fifteen entry points, but every call only
+// ENQUEUES device work on the caller's stream -- copy kernels through IPC-mapped rings, cross-process ordering by stream write / wait
+// values -- and returns, as RCCL's do.  The host-staged mode above stays the default and the fallback.
+//
 // Loaded through the product's own hook: CAPI_RCCL_LIB=<this .so> (capital_amd/driver.py -> capi_comm_load_rccl).
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -26,14 +30,23 @@
 #include <algorithm>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <map>
+
+#include "loopback_async.h"
 
 namespace {
+
+bool async_mode() {
+  static const bool on = [] { const char* e = getenv("CAPI_LOOPBACK_MODE"); return e && strcmp(e, "async") == 0; }();
+  return on;
+}
 
 struct LComm {
   std::string dir, name;
   int rank = 0, size = 1;
   std::vector<uint64_t> sent, recvd;     // per peer message counters: matching order on both sides is the only protocol
   int splits = 0;
+  lb_async::AComm* a = nullptr;          // asynchronous mode: this communicator's channels
 };
 
 double timeout_s() {
@@ -96,7 +109,40 @@ struct P2P { bool send; void* buf; size_t bytes; int peer; LComm* c; hipStream_t
 thread_local int g_depth = 0;
 thread_local std::vector<P2P> g_ops;
 
+// Asynchronous mode: the i-th send and the i-th receive of every (communicator, peer) go out in rounds -- all i-th sends, then all
+// i-th receives -- so that no send of a group ever stands in front of the receive its own ring slot is waiting for.
+ncclResult_t run_ops_async(std::vector<P2P>& ops) {
+  std::map<std::pair<LComm*, int>, int> nth_send, nth_recv;
+  std::vector<int> round(ops.size());
+  int rounds = 0;
+  for (size_t i = 0; i < ops.size(); ++i) {
+    auto& cnt = ops[i].send ? nth_send : nth_recv;
+    round[i] = cnt[{ops[i].c, ops[i].peer}]++;
+    rounds = std::max(rounds, round[i] + 1);
+  }
+  for (int r = 0; r < rounds; ++r) {
+    for (int pass = 0; pass < 2; ++pass)
+      for (size_t i = 0; i < ops.size(); ++i) {
+        P2P& o = ops[i];
+        if (round[i] != r || o.send != (pass == 0) || o.peer == o.c->rank) continue;
+        const bool ok = o.send ? lb_async::send(o.c->a, o.peer, o.buf, o.bytes, o.s) : lb_async::recv(o.c->a, o.peer, o.buf, o.bytes, o.s, false);
+        if (!ok) return ncclSystemError;
+      }
+    // a rank's messages to itself: the r-th send meets the r-th receive
+    for (size_t i = 0; i < ops.size(); ++i) {
+      if (round[i] != r || !ops[i].send || ops[i].peer != ops[i].c->rank) continue;
+      for (size_t j = 0; j < ops.size(); ++j)
+        if (round[j] == r && !ops[j].send && ops[j].c == ops[i].c && ops[j].peer == ops[j].c->rank) {
+          if (ops[j].bytes != ops[i].bytes || !lb_async::local_copy(ops[j].buf, ops[i].buf, ops[i].bytes, ops[j].s, false)) return ncclSystemError;
+          break;
+        }
+    }
+  }
+  return ncclSuccess;
+}
+
 ncclResult_t run_ops(std::vector<P2P>& ops) {
+  if (!ops.empty() && ops[0].c->a) return run_ops_async(ops);
   std::vector<char> host;
   for (auto& o : ops)
     if (o.send) { if (!d2h(host, o.buf, o.bytes, o.s) || !put(o.c, o.peer, host.data(), o.bytes)) return ncclSystemError; }
@@ -144,6 +190,7 @@ ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int
   c->sent.assign(nranks, 0);
   c->recvd.assign(nranks, 0);
   if (!barrier(c)) { delete c; return ncclSystemError; }
+  if (async_mode() && !(c->a = lb_async::attach(c->dir, c->name, rank, nranks))) { delete c; return ncclSystemError; }
   *comm = reinterpret_cast<ncclComm_t>(c);
   return ncclSuccess;
 }
@@ -169,6 +216,7 @@ ncclResult_t ncclCommSplit(ncclComm_t comm, int color, int key, ncclComm_t* newc
   c->rank = (int)(std::find(members.begin(), members.end(), p->rank) - members.begin());
   c->sent.assign(c->size, 0);
   c->recvd.assign(c->size, 0);
+  if (p->a && !(c->a = lb_async::attach(c->dir, c->name, c->rank, c->size))) { delete c; return ncclSystemError; }
   *newcomm = reinterpret_cast<ncclComm_t>(c);
   return ncclSuccess;
 }
@@ -176,6 +224,7 @@ ncclResult_t ncclCommSplit(ncclComm_t comm, int color, int key, ncclComm_t* newc
 ncclResult_t ncclCommDestroy(ncclComm_t comm) {
   LComm* c = L(comm);
   if (!c) return ncclInvalidArgument;
+  if (c->a) { lb_async::detach(c->a); c->a = nullptr; }
   if (c->name == "w") {
     // the world communicator goes last: once everybody is here the message directory can go (best effort)
     const bool all_here = barrier(c);
@@ -192,6 +241,13 @@ ncclResult_t ncclBroadcast(const void* send, void* recv, size_t count, ncclDataT
   LComm* c = L(comm);
   const size_t bytes = count * type_bytes(t);
   if (!c || !type_bytes(t) || root < 0 || root >= c->size) return ncclInvalidArgument;
+  if (c->a) {
+    if (c->rank == root) {
+      for (int r = 0; r < c->size; ++r) if (r != root && !lb_async::send(c->a, r, send, bytes, s)) return ncclSystemError;
+      return lb_async::local_copy(recv, send, bytes, s, false) ? ncclSuccess : ncclSystemError;
+    }
+    return lb_async::recv(c->a, root, recv, bytes, s, false) ? ncclSuccess : ncclSystemError;
+  }
   std::vector<char> host;
   if (c->rank == root) {
     if (!d2h(host, send, bytes, s)) return ncclSystemError;
@@ -208,6 +264,26 @@ ncclResult_t ncclBroadcast(const void* send, void* recv, size_t count, ncclDataT
 static ncclResult_t reduce_to(const void* send, void* recv, size_t count, ncclDataType_t t, ncclRedOp_t op, int root, bool all, LComm* c, hipStream_t s) {
   if (!c || t != ncclFloat64 || op != ncclSum || root < 0 || root >= c->size) return ncclInvalidArgument;
   const size_t bytes = count * sizeof(double);
+  if (c->a) {
+    // the same sum, (((x0 + x1) + x2) + ...) on `root`, by receive-side accumulation in rank order; then the broadcast back
+    if (c->rank == root) {
+      const void* own = send;
+      if (send == recv && root != 0) {                       // in place on a root that is not the first summand: its part is set aside first
+        void* tmp = lb_async::scratch(c->a, bytes);
+        if (!tmp || !lb_async::local_copy(tmp, send, bytes, s, false)) return ncclSystemError;
+        own = tmp;
+      }
+      for (int r = 0; r < c->size; ++r) {
+        const bool ok = r == root ? lb_async::local_copy(recv, own, bytes, s, r != 0) : lb_async::recv(c->a, r, recv, bytes, s, r != 0);
+        if (!ok) return ncclSystemError;
+      }
+      if (all) for (int r = 0; r < c->size; ++r) if (r != root && !lb_async::send(c->a, r, recv, bytes, s)) return ncclSystemError;
+    } else {
+      if (!lb_async::send(c->a, root, send, bytes, s)) return ncclSystemError;
+      if (all && !lb_async::recv(c->a, root, recv, bytes, s, false)) return ncclSystemError;
+    }
+    return ncclSuccess;
+  }
   std::vector<char> host;
   if (!d2h(host, send, bytes, s)) return ncclSystemError;
   if (c->rank == root) {
@@ -244,6 +320,15 @@ ncclResult_t ncclAllGather(const void* send, void* recv, size_t count, ncclDataT
   LComm* c = L(comm);
   const size_t bytes = count * type_bytes(t);
   if (!c || !type_bytes(t)) return ncclInvalidArgument;
+  if (c->a) {
+    for (int r = 0; r < c->size; ++r) if (r != c->rank && !lb_async::send(c->a, r, send, bytes, s)) return ncclSystemError;
+    for (int r = 0; r < c->size; ++r) {
+      char* dst = static_cast<char*>(recv) + (size_t)r * bytes;
+      const bool ok = r == c->rank ? lb_async::local_copy(dst, send, bytes, s, false) : lb_async::recv(c->a, r, dst, bytes, s, false);
+      if (!ok) return ncclSystemError;
+    }
+    return ncclSuccess;
+  }
   std::vector<char> mine, host;
   if (!d2h(mine, send, bytes, s)) return ncclSystemError;
   for (int r = 0; r < c->size; ++r) if (r != c->rank && !put(c, r, mine.data(), bytes)) return ncclSystemError;

@@ -8,7 +8,10 @@ case runs everywhere and sends even a 1-rank communicator through RCCL (CAPI_RCC
 
 The `loopback` cases run the same ranks, 2 (1x1x2) and 4 (2x2x1) of them, all on GPU 0, with tests/rccl_loopback standing in for
 librccl.so (RCCL proper refuses two ranks on one device): the product's kernels, packed wire formats, d > 1 base cases, K-class SUMMA
-and stream / event discipline then execute on a real MI355X on every 1-GPU box; only the transport is not RCCL's."""
+and stream / event discipline then execute on a real MI355X on every 1-GPU box; only the transport is not RCCL's.  The `_async` cases
+use its asynchronous mode (tests/rccl_loopback/loopback_async.hip): calls only enqueue device work on the caller's stream, as RCCL's
+do, so the consumer-side waits of the chunk pipelines (summa.h `P.wait`, cholinv.h EV_BC_*) are really needed -- and
+test_async_transport_catches_a_missing_consumer_wait shows that one dropped wait turns the parity check red there (and only there)."""
 import json
 import os
 import socket
@@ -39,7 +42,7 @@ def _free_port():
 LOOPBACK = os.path.join(HERE, "rccl_loopback", "librccl_loopback.so")
 
 
-def _launch(world, cfg, timeout=int(os.environ.get("CAPITAL_TEST_RANK_TIMEOUT_S", "900")), loopback=False):
+def _launch(world, cfg, timeout=int(os.environ.get("CAPITAL_TEST_RANK_TIMEOUT_S", "900")), loopback=False, extra_env=None, check=True):
     port = _free_port()
     procs = []
     for r in range(world):
@@ -49,8 +52,12 @@ def _launch(world, cfg, timeout=int(os.environ.get("CAPITAL_TEST_RANK_TIMEOUT_S"
             env["CAPI_RCCL_FORCE"] = "1"
         if loopback:
             env["CAPI_RCCL_LIB"] = LOOPBACK
+            env["CAPI_LOOPBACK_MODE"] = "async" if loopback == "async" else "host"
+            env.setdefault("CAPI_LOOPBACK_TIMEOUT_S", "90")
+        if extra_env:
+            env.update(extra_env)
         logdir = os.environ.get("CAPITAL_TEST_RANK_LOG_DIR")        # diagnostics: every rank's output into a file that survives a killed run
-        out = open(os.path.join(logdir, f"rank{r}_of{world}{'_loopback' if loopback else ''}.log"), "w") if logdir else subprocess.PIPE
+        out = open(os.path.join(logdir, f"rank{r}_of{world}{('_loopback_' + str(loopback)) if loopback else ''}.log"), "w") if logdir else subprocess.PIPE
         procs.append(subprocess.Popen([sys.executable, "-u", os.path.join(HERE, "_gpu_rank_main.py"), json.dumps(cfg)], env=env,
                                       stdout=out, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -68,15 +75,18 @@ def _launch(world, cfg, timeout=int(os.environ.get("CAPITAL_TEST_RANK_TIMEOUT_S"
     if timed_out:                                       # what every rank had printed when the limit struck (each case announces itself)
         outs = [p.communicate()[0] or "" for p in procs]
     outs = [o or "" for o in outs]
+    if not check:
+        return (not timed_out) and all(p.returncode == 0 for p in procs), outs
     assert not timed_out and all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
+    return True, outs
 
 
 # N -> c of the d x d x c grid: 1 = 1x1x1, 2 = 1x1x2 (K-slicing), 4 = 2x2x1 (two K-classes per layer), 8 = 2x2x2 (the reference's cubic case)
 GRID_C = {1: 1, 2: 2, 4: 1, 8: 2}
 
 
-@pytest.mark.parametrize("world,loopback", [(1, False), (2, False), (4, False), (8, False), (2, True), (4, True)],
-                         ids=["rccl1", "rccl2", "rccl4", "rccl8", "loopback2", "loopback4"])
+@pytest.mark.parametrize("world,loopback", [(1, False), (2, False), (4, False), (8, False), (2, "host"), (4, "host"), (2, "async"), (4, "async")],
+                         ids=["rccl1", "rccl2", "rccl4", "rccl8", "loopback2", "loopback4", "loopback2_async", "loopback4_async"])
 def test_cholinv_and_cacqr2_on_rccl(oracle, world, loopback):
     if loopback:
         subprocess.check_call(["make", "-C", os.path.dirname(LOOPBACK), "-s"])
@@ -109,6 +119,10 @@ def test_cholinv_and_cacqr2_on_rccl(oracle, world, loopback):
         cases.append({"tag": "ch_l1", "kind": "cholinv", "n": n, "c": c, "bc": -3, "ci": 1, "serialize": False, "policy": 0, "layout": 1})
     with tempfile.TemporaryDirectory() as d:
         _launch(world, {"dir": d, "cases": cases}, loopback=loopback)
+        _check_cases(oracle, d, cases, world, c)
+
+
+def _check_cases(oracle, d, cases, world, c):
         for case in cases:
             tag = case["tag"]
             if case["kind"] == "cholinv":
@@ -166,3 +180,48 @@ def test_cholinv_and_cacqr2_on_rccl(oracle, world, loopback):
                 assert info == 0
                 assert np.abs(Rg - Rref).max() <= 1e-12 * np.abs(Rref).max()
                 assert np.abs(Qg - Qref).max() <= 1e-12
+
+
+def _build_driver_without_consumer_wait(tmp):
+    """A copy of the host layer in which ONE line is gone -- the compute stream's wait for chunk j's broadcast in every chunk pipeline of
+    summa.h (`P.wait(EB + j);`, the consumer side of `P.rec(EB + j)`) -- compiled into a driver library of its own."""
+    import shutil
+    root = os.path.dirname(HERE)
+    for sub in ("src", "test", "drivers"):
+        shutil.copytree(os.path.join(root, "capital_amd", sub), os.path.join(tmp, sub))
+    summa = os.path.join(tmp, "src", "alg", "matmult", "summa", "summa.h")
+    text = open(summa).read()
+    assert text.count("P.wait(EB + j);") >= 3
+    open(summa, "w").write(text.replace("P.wait(EB + j);", "/* consumer wait removed by the negative test */"))
+    out = os.path.join(tmp, "libcapital_driver_nowait.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(root, "include"), os.path.join(tmp, "drivers", "capital_driver.cpp"),
+                           "-o", out, "-L" + os.path.join(root, "capital_amd"), "-lcapital_hip", "-Wl,-rpath," + os.path.join(root, "capital_amd")])
+    return out
+
+
+def test_async_transport_catches_a_missing_consumer_wait(oracle):
+    """The point of the asynchronous transport: a missing consumer-side wait must FAIL before real RCCL finds it.  The chunked Cholesky
+    of the parity cases runs on a driver whose chunk pipelines lack `P.wait(EB + j)` (the product's kernels and library otherwise):
+    over the host-staged transport, where every call has completed when it returns, the factors still match the oracle -- that
+    transport cannot see the bug; over the asynchronous one (receive-side copies delayed by 2 ms so the window is not a matter of luck)
+    they do not."""
+    subprocess.check_call(["make", "-C", os.path.dirname(LOOPBACK), "-s"])
+    world, c, n = 4, 1, 4096            # 2 x 2 x 1: row / column broadcasts feed every chunk
+    cases = [{"tag": "neg_chunks", "kind": "cholinv", "n": n, "c": c, "bc": -3, "ci": 1, "serialize": True, "policy": 0, "chunks": 3,
+              "env": {"CAPITAL_MULTIPATH": "0"}}]
+    with tempfile.TemporaryDirectory() as build:
+        lib = _build_driver_without_consumer_wait(build)
+        env = {"CAPITAL_DRIVER_LIB": lib}
+        with tempfile.TemporaryDirectory() as d:
+            _launch(world, {"dir": d, "cases": cases}, loopback="host", extra_env=env)
+            _check_cases(oracle, d, cases, world, c)                  # the synchronous stand-in is blind to it
+        with tempfile.TemporaryDirectory() as d:
+            ok, outs = _launch(world, {"dir": d, "cases": cases}, loopback="async",
+                               extra_env=dict(env, CAPI_LOOPBACK_DELAY_US="2000"), check=False)
+            caught = not ok
+            if ok:
+                try:
+                    _check_cases(oracle, d, cases, world, c)
+                except AssertionError:
+                    caught = True
+            assert caught, "the asynchronous transport did not expose the missing wait:\n" + "\n".join(o[-1500:] for o in outs)

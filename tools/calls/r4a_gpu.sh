@@ -1,9 +1,8 @@
 #!/bin/bash
-# round 3, last call: tall-skinny + RCCL single-rank tests at the final source (the T-stationary kernel was edited once more), CholeskyQR2 timing
-set -o pipefail
-export TMPDIR=/tmp
-O=gpurun_out/r4a
-mkdir -p $O
-python -m pytest tests/test_gpu_blas.py tests/test_gpu_schedules.py tests/test_gpu_rccl.py tests/test_golden.py tests/test_gpu_lapack.py -x -q -m gpu > $O/tests.log 2>&1; echo "tests rc=$?" | tee -a $O/summary.txt
-tail -3 $O/tests.log
-python tools/qr_ab2.py 22 15 > $O/ab2.log 2>&1; grep cacqr2 $O/ab2.log
+# round 4, call a: the asynchronous loopback transport -- parity cases on 2 and 4 ranks, then the negative test
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+mkdir -p gpurun_out/r4a_logs
+export CAPITAL_TEST_RANK_LOG_DIR=$PWD/gpurun_out/r4a_logs CAPITAL_TEST_RANK_TIMEOUT_S=400
+timeout -k 10 900 python -m pytest tests/test_gpu_multirank.py -x -q -k "async" > gpurun_out/r4a_pytest.log 2>&1
+echo "rc=$?" >> gpurun_out/r4a_pytest.log
+tail -40 gpurun_out/r4a_pytest.log

@@ -43,6 +43,7 @@ GRID_C = {1: 1, 2: 2, 4: 1, 8: 2}  # N -> c of the d x d x c grid (d*d*c = N): 1
 QR_CONFIG3 = (1 << 22, 256)       # BASELINE config 3 (one GPU)
 QR_CONFIG5_SLICE = (1 << 23, 1024)  # rows per GPU and width of BASELINE config 5 (m = 2^26 on 8 GPUs)
 BASE_CASE_ORDER = 1024            # aggregated order of the recursion's base case on every grid
+T_START, BUDGET_S = 0.0, 480.0    # set in main()
 
 
 def barrier_sync(distributed):
@@ -240,6 +241,10 @@ def main():
                                     timeout_s=float(os.environ.get("CAPITAL_BENCH_WATCHDOG_S", "1500")) + 120))
     from capital_amd import launch
     launch.die_with_parent()
+    global T_START, BUDGET_S
+    T_START = time.perf_counter()
+    # overall budget of one bench process: probes and extras that would start beyond it are skipped and say so in the line
+    BUDGET_S = float(os.environ.get("CAPITAL_BENCH_BUDGET_S", "480"))
 
     # a hung collective must end the run with a traceback and a non-zero exit, not sit on the node until the driver's limit
     import faulthandler
@@ -283,8 +288,9 @@ def main():
     # (multi-path pair transfers over all xGMI links, the chunked SUMMA pipeline on a second stream, both) gets one warm-up and one timed
     # step; the fastest one that validates (residual <= 1e-14) and beats the plain form by > 2 % is timed in full and reported, with the
     # whole table in `config.comm_forms`.  CAPITAL_BENCH_FORM=<name> pins a form (no probing); CAPITAL_BENCH_CHUNKS=<k> pins the pipeline
-    # depth of the plain form as before.  If a probe does not come back within CAPITAL_BENCH_PROBE_S (default 300 s), rank 0 prints the
-    # plain form's line and every rank leaves: a new code path must not cost the node's number.
+    # depth of the plain form as before.  Every probe runs under its own timer (CAPITAL_BENCH_PROBE_S, default 120 s, armed and cancelled at
+    # the same program points on every rank): if one does not come back, rank 0 prints the plain form's line WITH the hung form recorded
+    # (`probe_hang`, config.comm_forms) and every rank exits with code 3.  Probes that would start beyond CAPITAL_BENCH_BUDGET_S are skipped.
     forms = [("plain", int(os.environ.get("CAPITAL_BENCH_CHUNKS", "0")), False)]
     if distributed and "CAPITAL_BENCH_CHUNKS" not in os.environ:
         forms += [("chunks4", 4, False), ("chunks8", 8, False)]
@@ -301,23 +307,50 @@ def main():
     comm_forms = [{"form": name, "chunks": chunks, "multipath": mp, "ms_per_step": r["ms_per_step"], "residual": r["residual"], "timed": "full"}]
     if len(forms) > 1:
         import threading
-        safe_line = json.dumps(make_line(args, n, bc, r, chunks, mp, rccl, max_over_ranks(r["residual"], distributed, device), comm_forms,
-                                         recorded_traffic(n, args.gpus)))
+        plain_r = r
+        state = {"form": None}
 
-        def bail():      # a probe hangs: the line that exists goes out, everybody leaves (exit 0: the measurement of the plain form is valid)
+        def bail():
+            # A probe did not return: a hung collective of a communication form that has never met this node.  The plain form's measurement is
+            # valid and goes out -- WITH the hang recorded in config.comm_forms and in `probe_hang` -- and every rank leaves with exit code 3:
+            # the records must show the hang, a clean exit would bury it.
+            hung = {"form": state["form"], "error": f"no return within {probe_s:.0f} s (hung collective?)"}
             if rank == 0:
-                print(safe_line, flush=True)
-            sys.stderr.write(f"bench.py: rank {rank}: a communication-form probe did not return; reporting the plain form\n")
+                line = make_line(args, n, bc, plain_r, forms[0][1], forms[0][2], rccl, plain_r["residual"], comm_forms + [hung], recorded_traffic(n, args.gpus))
+                line["probe_hang"] = hung
+                print(json.dumps(line), flush=True)
+            sys.stderr.write(f"bench.py: rank {rank}: probe of form {state['form']!r} did not return within {probe_s:.0f} s; the plain form's line is reported, exit code 3\n")
             sys.stderr.flush()
-            os._exit(0)
-        timer = threading.Timer(float(os.environ.get("CAPITAL_BENCH_PROBE_S", "300")), bail)
-        timer.daemon = True
-        timer.start()
+            os._exit(3)
+        probe_s = float(os.environ.get("CAPITAL_BENCH_PROBE_S", "120"))
+
+        def probe(fname, *a, **kw):
+            """one probe under its OWN timer, armed on every rank at the same point of the program and cancelled only behind a barrier: either
+            every rank's timer is cancelled or every rank's fires (a rank that cancelled early would sit alone in the next collective)"""
+            state["form"] = fname
+            timer = threading.Timer(probe_s, bail)
+            timer.daemon = True
+            timer.start()
+            try:
+                pr = time_cholesky(*a, **kw)
+                okv = max_over_ranks(pr["residual"], distributed, device) <= 1e-14
+            finally:
+                barrier_sync(distributed)
+                timer.cancel()
+            return pr, okv
+
+        def out_of_budget(what, est_s):
+            if time.perf_counter() - T_START + est_s <= BUDGET_S:
+                return False
+            comm_forms.append({"form": what, "skipped": f"overall budget CAPITAL_BENCH_BUDGET_S={BUDGET_S:.0f} s"})
+            return True
+        est = 3.0 * r["ms_per_step"] * 1e-3 + 20.0          # a probe = set-up + warm-up + one step (+ validation)
         best = None
         for fname, fch, fmp in forms[1:]:
+            if out_of_budget(fname, est):
+                continue
             try:
-                pr = time_cholesky(driver, L, h, n, c, bc, fch, 1, 1, distributed, device, bc_policy=0, multipath=fmp)
-                ok = max_over_ranks(pr["residual"], distributed, device) <= 1e-14
+                pr, ok = probe(fname, driver, L, h, n, c, bc, fch, 1, 1, distributed, device, bc_policy=0, multipath=fmp)
                 comm_forms.append({"form": fname, "chunks": fch, "multipath": fmp, "ms_per_step": pr["ms_per_step"], "residual": pr["residual"],
                                    "timed": "1 step", "valid": ok})
                 if ok and (best is None or pr["ms_per_step"] < best[3]):
@@ -332,11 +365,10 @@ def main():
         if args.bc is None and not pinned:
             for order in (2 * BASE_CASE_ORDER, 4 * BASE_CASE_ORDER):
                 obc = bc_mult_for(n, d, c, order)
-                if obc == bc:
+                if obc == bc or out_of_budget(f"{cur[0]} @ base case {order}", est):
                     continue
                 try:
-                    pr = time_cholesky(driver, L, h, n, c, obc, cur[1], 1, 1, distributed, device, bc_policy=0, multipath=cur[2])
-                    ok = max_over_ranks(pr["residual"], distributed, device) <= 1e-14
+                    pr, ok = probe(f"{cur[0]} @ base case {order}", driver, L, h, n, c, obc, cur[1], 1, 1, distributed, device, bc_policy=0, multipath=cur[2])
                     comm_forms.append({"form": cur[0], "chunks": cur[1], "multipath": cur[2], "base_case_order": pr["stats"]["bc_dimension"],
                                        "ms_per_step": pr["ms_per_step"], "residual": pr["residual"], "timed": "1 step", "valid": ok})
                     if ok and pr["ms_per_step"] < cur[3] and (best_bc is None or pr["ms_per_step"] < best_bc[1]):
@@ -344,23 +376,42 @@ def main():
                 except Exception as e:
                     comm_forms.append({"form": cur[0], "base_case_order": order, "error": repr(e)[:200]})
         final_ms = best_bc[1] if best_bc else cur[3]
-        if final_ms < 0.98 * r["ms_per_step"]:
+        full_est = (args.steps + args.warmup + 1) * final_ms * 1e-3 + 20.0
+        if final_ms < 0.98 * r["ms_per_step"] and not out_of_budget(f"{cur[0]} (full re-run)", full_est):
             name, chunks, mp = cur[:3]
             if best_bc:
                 bc = best_bc[0]
             plain = (forms[0][0], forms[0][1], forms[0][2], r, bc_mult_for(n, d, c, BASE_CASE_ORDER) if args.bc is None else args.bc)
-            r = time_cholesky(driver, L, h, n, c, bc, chunks, args.steps, args.warmup, distributed, device, bc_policy=0, multipath=mp)
+            state["form"] = f"{name} (full re-run)"
+            timer = threading.Timer(probe_s + full_est, bail)
+            timer.daemon = True
+            timer.start()
+            try:
+                r = time_cholesky(driver, L, h, n, c, bc, chunks, args.steps, args.warmup, distributed, device, bc_policy=0, multipath=mp)
+            finally:
+                barrier_sync(distributed)
+                timer.cancel()
             comm_forms.append({"form": name, "chunks": chunks, "multipath": mp, "base_case_order": r["stats"]["bc_dimension"],
                                "ms_per_step": r["ms_per_step"], "residual": r["residual"], "timed": "full"})
             # the full run of the chosen form must validate and must still be the faster one: else the plain form's measurement stands
             if max_over_ranks(r["residual"], distributed, device) > 1e-14 or r["ms_per_step"] >= plain[3]["ms_per_step"]:
                 name, chunks, mp, r, bc = plain
                 comm_forms.append({"form": name, "note": "reported: the chosen form's full run did not validate or was not faster"})
-        timer.cancel()
     residual_max = max_over_ranks(r["residual"], distributed, device)
     out = make_line(args, n, bc, r, chunks, mp, rccl, residual_max, comm_forms if distributed else None, recorded_traffic(n, args.gpus))
+    skipped = []
 
-    if args.gpus == 1 and not args.no_config2 and not args.n:
+    def in_budget(what, est_s):
+        """extras beyond the headline start only while the process is inside CAPITAL_BENCH_BUDGET_S; what is skipped is named in the line
+        (every rank takes the same decision at the same point: the clocks differ by less than the margins in the estimates)"""
+        t = max_over_ranks(time.perf_counter() - T_START, distributed, device)
+        if t + est_s <= BUDGET_S:
+            return True
+        skipped.append(what)
+        return False
+    step_s = r["ms_per_step"] * 1e-3
+
+    if args.gpus == 1 and not args.no_config2 and not args.n and in_budget("config2", 12 * step_s / 7 + 20):
         n2 = 32768
         r2 = time_cholesky(driver, L, h, n2, 1, bc_mult_for(n2, 1, 1, BASE_CASE_ORDER), 0, max(args.steps, 3), 1, False, device, bc_policy=2)
         k2 = r2["kernel"]
@@ -371,14 +422,14 @@ def main():
         r2t = time_cholesky(driver, L, h, n2, 1, bc_mult_for(n2, 1, 1, BASE_CASE_ORDER), 0, max(args.steps, 3), 1, False, device, bc_policy=2, trsm_mode=True)
         out["config2"]["trsm_mode"] = {"tflops": r2t["tflops"], "ms_per_step": r2t["ms_per_step"], "residual": r2t["residual"]}
 
-    if args.gpus == 1 and not args.no_config2 and not args.n:
+    if args.gpus == 1 and not args.no_config2 and not args.n and in_budget("cholesky_trsm_mode", 4 * step_s + 15):
         # NOT the headline: the same matrix factored without forming any inverse (info::solve_with_trsm: potrf + block TRSM + SYRK,
         # what BASELINE north_star names; executes n^3/3 instead of the reference schedule's 5 n^3/12).  Same R, no R^-1.
         rt = time_cholesky(driver, L, h, n, 1, bc, 0, 2, 1, False, device, bc_policy=2, trsm_mode=True)
         out["cholesky_trsm_mode"] = {"workload": f"n={n} Cholesky, TRSM mode (R only, no inverse formed), 1 GPU", "tflops": rt["tflops"],
                                      "ms_per_step": rt["ms_per_step"], "residual": rt["residual"]}
 
-    if distributed and not args.no_config2 and not os.environ.get("CAPITAL_BENCH_NO_TRSM_GRID"):
+    if distributed and not args.no_config2 and not os.environ.get("CAPITAL_BENCH_NO_TRSM_GRID") and in_budget("cholesky_trsm_mode", 5 * step_s + 20):
         # NOT the headline: TRSM mode on the grid (cholinv.h: potrf_rec_grid; d == 1: every layer factors the replicated matrix) -- an extra;
         # its failure must not take the line with it (a driver error raises on every rank alike)
         try:
@@ -389,7 +440,7 @@ def main():
         except Exception as e:
             out["cholesky_trsm_mode"] = {"error": repr(e)[:300]}
 
-    if not args.no_qr:
+    if not args.no_qr and in_budget("cacqr2 / cacqr2_config5", 60):
         reps = max(args.steps, 3)
         if args.gpus == 1:
             m3, n3 = QR_CONFIG3
@@ -409,6 +460,8 @@ def main():
                                  "algorithmic_GBps_per_gpu": 6 * 8.0 * m_loc * n5 / (q5["ms"] * 1e-3) / 1e9,
                                  "residual": max_over_ranks(q5["residual"], distributed, device), "orthogonality": q5["orthogonality"]}
 
+    if skipped:
+        out["skipped_for_budget"] = {"budget_s": BUDGET_S, "legs": skipped}
     if rank == 0:
         # register-only MFMA loop, two waves per SIMD, >= 100 ms: what the matrix pipe sustains on THIS device's clocks
         peak = C.c_double()

@@ -69,6 +69,7 @@ _SIGS = {
     "capi_reserve_workspace": [C.c_size_t],
     "capi_trim_workspaces": [],
     "capi_set_launch_rounds": [_int, C.POINTER(_int)],
+    "capi_reserve_cus": [_int],
     "capi_memset_async": [_vp, _int, C.c_size_t],
     "capi_memcpy_h2d": [_vp, _vp, C.c_size_t],
     "capi_memcpy_d2h": [_vp, _vp, C.c_size_t],

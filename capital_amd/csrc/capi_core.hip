@@ -4,6 +4,8 @@
 #include <stdlib.h>
 #include "capi_internal.h"
 
+static void graphs_invalidate(capi_handle_t h);
+
 extern "C" {
 
 int capi_version(void) { return 100; }
@@ -173,7 +175,13 @@ int capi_stream_select(capi_handle_t h, int which) {
   if (which >= 1 && !h->streams[which]) {
     CAPI_HIP_CHECK(h, hipSetDevice(h->device));
     if (which == 1) {
-      CAPI_HIP_CHECK(h, hipStreamCreateWithFlags(&h->streams[1], hipStreamNonBlocking));
+      // The communication stream carries RCCL's kernels (and packing copies): few, short-lived or few-workgroup launches that a chunk
+      // pipeline is waiting for.  Highest priority, like the compute stream: whenever the dispatcher has a free slot and both queues hold
+      // work, theirs goes first -- a tile launch of thousands of workgroups behind it loses nothing (CAPI_COMM_PRIO_NORMAL: default priority,
+      // A/B; measured in profiles/r4_overlap_*: what decides is whether a slot is free at all, see capi_reserve_cus).
+      int least = 0, greatest = 0;
+      CAPI_HIP_CHECK(h, hipDeviceGetStreamPriorityRange(&least, &greatest));
+      CAPI_HIP_CHECK(h, hipStreamCreateWithPriority(&h->streams[1], hipStreamNonBlocking, getenv("CAPI_COMM_PRIO_NORMAL") ? 0 : greatest));
     } else {
       // Bulk streams run long MFMA tile kernels beside the compute stream's latency-bound chain: lowest priority.
       // A tile workgroup owns a whole CU (512 threads x 256 VGPRs) and the workgroups of one launch finish in rounds, so
@@ -199,6 +207,40 @@ int capi_stream_select(capi_handle_t h, int which) {
   h->cur = which;
   return CAPI_OK;
 }
+// Keep the handle's COMPUTE stream off `reserve` CUs (0: all CUs again).  A 128-tile workgroup owns half a CU's registers for its whole
+// life and a launch refills every slot the moment it frees, so kernels of another stream -- RCCL's send/recv kernels on the communication
+// stream of a grid run -- find no slot before a resident round ends (stream priorities only order the dispatcher's choices, they free
+// nothing).  With a CU mask on the compute stream those kernels start at once, on CUs the tile kernel never touches; the tile launches
+// count their rounds on the remaining CUs (cu_of).  Mask bit b is CU b / 8 of XCD b % 8: the reserve is spread evenly over the XCDs.
+// Only for handles that own their compute stream; drains the handle's streams.
+int capi_reserve_cus(capi_handle_t h, int reserve) {
+  CAPI_REQUIRE(h, h && reserve >= 0 && reserve < h->num_cu && reserve % 8 == 0, "reserve: a multiple of 8 below the CU count");
+  CAPI_REQUIRE(h, h->owns_stream, "the compute stream belongs to the caller");
+  CAPI_HIP_CHECK(h, hipSetDevice(h->device));
+  int rc = capi_sync(h);
+  if (rc != CAPI_OK) return rc;
+  if ((h->cu_of[0] ? h->num_cu - h->cu_of[0] : 0) == reserve) return CAPI_OK;
+  graphs_invalidate(h);
+  hipStream_t fresh = nullptr;
+  int least = 0, greatest = 0;
+  CAPI_HIP_CHECK(h, hipDeviceGetStreamPriorityRange(&least, &greatest));
+  if (reserve == 0) {
+    CAPI_HIP_CHECK(h, hipStreamCreateWithPriority(&fresh, hipStreamNonBlocking, greatest));
+  } else {
+    const int keep = h->num_cu - reserve;
+    uint32_t mask[16] = {0};
+    for (int b = 0; b < keep && b < 512; ++b) mask[b >> 5] |= 1u << (b & 31);
+    CAPI_HIP_CHECK(h, hipExtStreamCreateWithCUMask(&fresh, (uint32_t)((h->num_cu + 31) / 32), mask));
+  }
+  hipStream_t old = h->streams[0] ? h->streams[0] : h->stream;
+  const bool selected = h->cur == 0;
+  if (h->streams[0]) h->streams[0] = fresh;
+  if (selected) h->stream = fresh;
+  h->cu_of[0] = reserve ? h->num_cu - reserve : 0;
+  CAPI_HIP_CHECK(h, hipStreamDestroy(old));
+  return CAPI_OK;
+}
+
 static int event_slot(capi_handle_t h, int slot, hipEvent_t** ev) {
   CAPI_REQUIRE(h, h && slot >= 0 && slot < 1024, "event slot");
   if (!h->events) {
@@ -288,9 +330,12 @@ static void graphs_invalidate(capi_handle_t h) {
 static int ws_grow(capi_handle_t h, void** slot, size_t* cap, size_t bytes, void** p) {
   if (!h || !p) return CAPI_EINVAL;
   if (bytes > *cap) {
-    graphs_invalidate(h);
-    // stream-ordered users of the old block must finish before it is released
+    // stream-ordered users of the old block must finish before it is released -- and a captured chain that was replayed just before may still
+    // be in flight on any of the handle's streams: everything drains first, only then are the captured chains dropped
+    for (int i = capi_handle_s::NSTREAMS - 1; i >= 0; --i)
+      if (h->streams[i] && h->streams[i] != h->stream) CAPI_HIP_CHECK(h, hipStreamSynchronize(h->streams[i]));
     CAPI_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    graphs_invalidate(h);
     if (*slot) CAPI_HIP_CHECK(h, hipFree(*slot));
     *slot = nullptr;
     *cap = 0;

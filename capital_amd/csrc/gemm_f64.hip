@@ -1779,7 +1779,7 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
   // (bit 0: plain products; bit 1: triangular outputs in the banded order -- an XCD's 64 tiles of a round are an 8 x 8 block of the triangle)
   // (the 256-column block launches of a tall right-TRMM were tried the same way: a round there is 512 tiles of K <= 1024, ~0.15 ms, and the
   //  launch boundaries cost 11 %: 35.1 -> 39.2 ms at m = 2^21, n = 1024; r3s)
-  const bool use_rounds = p.ts == 128 && p.splitk == 1 && !tri && per_round == 512 && p.batch <= 1 && (int64_t)p.ntiles >= 2 * per_round &&
+  const bool use_rounds = p.ts == 128 && p.splitk == 1 && !tri && per_round % 16 == 0 && p.batch <= 1 && (int64_t)p.ntiles >= 2 * per_round &&
                           (p.out_uplo < 0 ? (rounds_mode & 1) != 0 : ((rounds_mode & 2) != 0 && (p.order & 1)));      // (see "Resident rounds" below)
   int tail128 = 0;
   if (p.ts == 128 && p.splitk == 1 && !tri && !getenv("CAPI_NO_TAIL")) {

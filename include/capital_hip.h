@@ -65,6 +65,9 @@ int  capi_trim_workspaces(capi_handle_t h);
  * all run on one stream (grids, the TRSM mode); on = 0: the handle's defaults (environment: CAPI_ROUNDS, CAPI_TRMM_PAIR, CAPI_TRMM_PAIR_ROUNDS).
  * *was (may be NULL) receives the previous setting. */
 int  capi_set_launch_rounds(capi_handle_t h, int on, int* was);
+/* keep the handle's compute stream off `reserve` CUs (a multiple of 8; 0 = all CUs again): the communication stream's kernels (RCCL's
+ * send/recv on a grid) then start at once beside a tile launch instead of at its next round boundary.  Drains the handle's streams. */
+int  capi_reserve_cus(capi_handle_t h, int reserve);
 
 /* ---- BLAS layer: replaces blas::engine::_gemm/_trmm/_syrk (src/blas/interface.h:58-66,
  *      src/blas/interface.hpp:43-97 -> cblas_dgemm/dtrmm/dsyrk) ---- */

@@ -16,3 +16,16 @@ a, b = ends[W - 1] + 1 if W > 0 else 0, ends[W + K - 1]
 timed = [r for r in rows[a:b + 1] if sym in r["Kernel_Name"]]
 d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in timed]
 print(f"{sym}: {len(d)} launches in the {K} timed factor() calls, {len(d) / K:.1f} per call, average {sum(d) / len(d) / 1e6:.4f} ms, max {max(d) / 1e6:.3f} ms")
+# union of the launches' execution intervals (what bench.py's roofline.union_ms_per_step is, from the kernels' own stamps): launches of
+# several streams interleave round by round, so the sum of the durations exceeds the time the kernel was on the device
+iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in timed)
+cov, ca, cb = 0, None, None
+for s_, e_ in iv:
+    if ca is None or s_ > cb:
+        if ca is not None:
+            cov += cb - ca
+        ca, cb = s_, e_
+    elif e_ > cb:
+        cb = e_
+cov += (cb - ca) if ca is not None else 0
+print(f"{sym}: per call: union of the intervals {cov / K / 1e6:.3f} ms, sum of the durations {sum(d) / K / 1e6:.3f} ms")

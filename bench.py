@@ -92,21 +92,17 @@ def cpu_baseline(n_sample, m_sample, qn):
 
 
 def recorded_traffic(n, gpus):
-    """L2-to-fabric bytes per launch of the roofline kernel from the committed PMC passes of the same configuration
+    """L2-to-fabric bytes per launch of the roofline kernel (both of its symbols) from the committed PMC passes of the same configuration
     (2 x FETCH_SIZE + WRITE_SIZE on gfx950; profiles/README.md).  Counters cannot be read from inside a timed run, so this is
-    a RECORDED figure (`traffic_source` names the files), or None when no pass of this configuration is committed."""
+    a RECORDED figure (`traffic_source` names the files), or None when no pass of this configuration AND launch form is committed."""
     import csv
-    # (file pattern, trailing rows that belong to the residual check's products rather than to factor())
-    tag, drop = {(65536, 1): ("r3_pmc_{}_bench_n65536.csv", 0), (32768, 1): ("r1_d_pmc_{}_bench_step.csv", 1)}.get((n, gpus), (None, 0))
-    if tag is None:
-        return None, None
-    if not os.path.exists(os.path.join(ROOT, "profiles", tag.format("fe"))):
-        tag = tag.replace("r3_", "r2_")              # (the previous round's capture until this round's is committed)
+    if (n, gpus) != (65536, 1) or os.environ.get("CAPITAL_NO_LAUNCH_ROUNDS"):
+        return None, None          # the committed passes describe the default form: launches in resident rounds, n = 65536 on one GPU
+    tag = "r4_pmc_{}_bench_n65536.csv"
     tot, launches = 0.0, 0
     try:
         for t, name in (("fe", "FETCH_SIZE"), ("wr", "WRITE_SIZE")):
             rows = [r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", tag.format(t)))) if r["Counter_Name"] == name]
-            rows = rows[:len(rows) - drop]
             launches = len(rows)
             tot += sum(float(r["Counter_Value"]) for r in rows) * 1024 * (2 if name == "FETCH_SIZE" else 1)
     except (OSError, KeyError, ValueError):
@@ -115,14 +111,31 @@ def recorded_traffic(n, gpus):
         return None, None
     commit = ""
     try:
-        commit = open(os.path.join(ROOT, "profiles", tag[:2] + "_capture_commit.txt")).read().split()[0]
+        commit = open(os.path.join(ROOT, "profiles", "r4_capture_commit.txt")).read().split()[0]
     except (OSError, IndexError):
         pass
-    return tot / launches, (f"recorded: profiles/{tag.format('{fe,wr}')}: 2 x FETCH_SIZE + WRITE_SIZE, mean of the {launches} launches of one factor()"
-                            + (f"; captured at commit {commit}" if commit else ""))
+    return tot / launches, (f"recorded: profiles/{tag.format('{fe,wr}')}: 2 x FETCH_SIZE + WRITE_SIZE, mean of the {launches} launches (resident rounds) of one factor(), "
+                            f"both symbols; {tot / 1e9:.0f} GB per factor()" + (f"; captured at commit {commit}" if commit else ""))
+
+
+def leg_starts(tag):
+    """diagnostics (CAPITAL_BENCH_DUMP_MAPS=<file>): which leg the process is in and, rewritten at every leg, its memory map -- a fault address
+    from a profiler's crash report can then be attributed to a module (the rocprofv3 --pmc host SIGSEGV, profiles/README.md)"""
+    path = os.environ.get("CAPITAL_BENCH_DUMP_MAPS")
+    if not path:
+        return
+    sys.stderr.write(f"bench.py: leg {tag} starts at +{time.perf_counter() - T_START:.1f} s\n")
+    sys.stderr.flush()
+    try:
+        with open("/proc/self/maps") as f, open(path, "w") as g:
+            g.write(f"# /proc/self/maps of pid {os.getpid()} at the start of leg {tag}\n")
+            g.write(f.read())
+    except OSError:
+        pass
 
 
 def time_cholesky(driver, L, h, n, c, bc, chunks, steps, warmup, distributed, device, bc_policy, trsm_mode=False, multipath=None):
+    leg_starts(f"cholesky n={n} grid c={c} chunks={chunks}" + (" TRSM mode" if trsm_mode else ""))
     if multipath is not None:          # read by topo::square when the grid object is built (capital_amd/src/util/topology.h)
         # "kslice": the replicated 2-GPU grid by K-slices + depth all-reduce instead of by output columns (summa.h: colsplit)
         os.environ.pop("CAPITAL_KSLICE", None)
@@ -148,22 +161,26 @@ def time_cholesky(driver, L, h, n, c, bc, chunks, steps, warmup, distributed, de
     L.capi_prof_collect(h, 11, C.byref(launches), C.byref(tot_ms), C.byref(tot_fl), C.byref(max_ms))   # 8 + 3: the 128-tile TN kernel, one symbol
     allv = [C.c_int64(), C.c_double(), C.c_double()]
     L.capi_prof_collect(h, -1, C.byref(allv[0]), C.byref(allv[1]), C.byref(allv[2]), None)
-    # the same launches timed by the kernel itself (first workgroup's start .. last workgroup's end): union and sum of the intervals
-    iv = [C.c_int64(), C.c_double(), C.c_double(), C.c_double(), C.c_double()]
-    L.capi_prof_collect_intervals(h, 11, C.byref(iv[0]), C.byref(iv[1]), C.byref(iv[2]), C.byref(iv[3]), C.byref(iv[4]))
-    iva = [C.c_int64(), C.c_double(), C.c_double(), C.c_double()]
-    L.capi_prof_collect_intervals(h, -1, C.byref(iva[0]), C.byref(iva[1]), C.byref(iva[2]), C.byref(iva[3]), None)
+    # the same launches timed by the kernels themselves (first workgroup's start .. last workgroup's end): union and sum of the intervals.
+    # 103 = the 128-tile kernels on k-contiguous operands, TWO symbols with one inner loop: dgemm_tile_kernel<128,true,true> (trailing
+    # updates; TRMMs when launched one product at a time) and dtrmm_pair_kernel<true,true> (the R12 products as equal-work tile pairs, the form
+    # resident rounds need); 11 and 27 = each symbol alone
+    def intervals(code):
+        v = [C.c_int64(), C.c_double(), C.c_double(), C.c_double(), C.c_double()]
+        L.capi_prof_collect_intervals(h, code, C.byref(v[0]), C.byref(v[1]), C.byref(v[2]), C.byref(v[3]), C.byref(v[4]))
+        return {"launches": v[0].value, "union_ms": v[1].value, "sum_ms": v[2].value, "flops": v[3].value, "max_ms": v[4].value}
+    iv, iv_tile, iv_pair, iva = intervals(103), intervals(11), intervals(27), intervals(-1)
     ms = dt / steps * 1e3
     res = {"ms_per_step": ms, "tflops": n ** 3 / 3.0 / (ms * 1e-3) / 1e12, "residual": prob.residual(), "stats": prob.stats(),
            "grid": [prob.d, prob.d, prob.c],
            "kernel": {"launches": launches.value, "ms": tot_ms.value, "flops": tot_fl.value, "max_ms": max_ms.value, "all_tile_ms": allv[1].value,
-                      "iv_launches": iv[0].value, "iv_union_ms": iv[1].value, "iv_sum_ms": iv[2].value, "iv_flops": iv[3].value, "iv_max_ms": iv[4].value,
-                      "iv_all_union_ms": iva[1].value}}
+                      "iv": iv, "iv_tile": iv_tile, "iv_pair": iv_pair, "iv_all": iva}}
     prob.close()
     return res
 
 
 def time_cacqr2(driver, m, n, reps, distributed, device):
+    leg_starts(f"cacqr2 {m} x {n}")
     q = driver.Cacqr(m, n, c=1, variant=2)
     q.generate()
     q.factor()
@@ -188,7 +205,14 @@ def make_line(args, n, bc, r, chunks, multipath, rccl, residual_max, comm_forms,
     # launches' own execution intervals, capi_prof_collect_intervals).  The launches of the lookahead's bulk streams go out one resident
     # round at a time and interleave: stream-ordered HIP-event brackets then also contain the neighbours' rounds (`by_event_brackets`).
     by_events = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
-    achieved = k["iv_flops"] / (k["iv_union_ms"] * 1e-3) / 1e12 if k.get("iv_union_ms", 0) > 0 else by_events
+    iv = k["iv"]
+    achieved = iv["flops"] / (iv["union_ms"] * 1e-3) / 1e12 if iv["union_ms"] > 0 else by_events
+    steps = max(args.steps, 1)
+
+    def sym(name, v):
+        return {"symbol": name, "launches_per_step": v["launches"] / steps, "avg_launch_ms": v["sum_ms"] / max(v["launches"], 1),
+                "algorithmic_tflops_per_step": v["flops"] / steps / 1e12,
+                "rate_over_own_union": v["flops"] / (v["union_ms"] * 1e-3) / 1e12 if v["union_ms"] > 0 else None}
 
     out = {
         "metric": "TFLOP/s (whole node) Cholesky n=65536, algorithmic n^3/3, recursive cholinv factor(), inputs resident in HBM",
@@ -204,15 +228,18 @@ def make_line(args, n, bc, r, chunks, multipath, rccl, residual_max, comm_forms,
                    "rccl_world": list(rccl) if rccl else None},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": "dgemm_tile_kernel<128,true,true> (trailing update + R12 solve, orders >= 4096)",
-                     "timed_by": "the kernel's own wall-clock stamps (first workgroup start .. last workgroup end of every launch); achieved = sum of "
+                     "timed_by": "the kernels' own wall-clock stamps (first workgroup start .. last workgroup end of every launch); achieved = sum of "
                                  "algorithmic flops / length of the union of the launches' intervals",
-                     "launches_per_step": k["iv_launches"] / max(args.steps, 1),
-                     "avg_launch_ms": k["iv_sum_ms"] / max(k["iv_launches"], 1), "max_launch_ms": k["iv_max_ms"],
-                     "union_ms_per_step": k["iv_union_ms"] / max(args.steps, 1), "sum_ms_per_step": k["iv_sum_ms"] / max(args.steps, 1),
-                     "avg_flops_per_launch": k["iv_flops"] / max(k["iv_launches"], 1),
-                     "by_event_brackets": {"achieved": by_events, "ms_per_step": k["ms"] / max(args.steps, 1), "launches": k["launches"]},
-                     "tile_kernels_share_of_step": k["iv_all_union_ms"] / (r["ms_per_step"] * args.steps) if r["ms_per_step"] > 0 else None},
+                     "kernel": "the 128-tile MFMA kernel on k-contiguous operands (trailing update + R12 product, orders >= 4096): "
+                               "dgemm_tile_kernel<128,true,true> and its tile-pair form dtrmm_pair_kernel<true,true>",
+                     "symbols": [sym("dgemm_tile_kernel<128, true, true>", k["iv_tile"]), sym("dtrmm_pair_kernel<true, true>", k["iv_pair"])],
+                     "launches_per_step": iv["launches"] / steps, "avg_launch_ms": iv["sum_ms"] / max(iv["launches"], 1), "max_launch_ms": iv["max_ms"],
+                     "union_ms_per_step": iv["union_ms"] / steps, "sum_ms_per_step": iv["sum_ms"] / steps,
+                     "avg_flops_per_launch": iv["flops"] / max(iv["launches"], 1),
+                     "by_event_brackets": {"achieved": by_events, "ms_per_step": k["ms"] / steps, "launches": k["launches"],
+                                           "note": "HIP events around every launch of dgemm_tile_kernel<128,true,true> alone: stream-ordered, so a bracket "
+                                                   "also holds whatever other streams ran between its two events"},
+                     "all_tile_kernels_union_share_of_step": k["iv_all"]["union_ms"] / (r["ms_per_step"] * args.steps) if r["ms_per_step"] > 0 else None},
     }
     return out
 
@@ -417,7 +444,7 @@ def main():
         k2 = r2["kernel"]
         out["config2"] = {"workload": f"n={n2} recursive Cholesky with inverse on 1 GPU (BASELINE config 2)", "tflops": r2["tflops"],
                           "ms_per_step": r2["ms_per_step"], "residual": r2["residual"],
-                          "roofline_kernel_tflops": k2["flops"] / (k2["ms"] * 1e-3) / 1e12 if k2["ms"] > 0 else None}
+                          "roofline_kernel_tflops": k2["iv"]["flops"] / (k2["iv"]["union_ms"] * 1e-3) / 1e12 if k2["iv"]["union_ms"] > 0 else None}
         # BASELINE words config 2 as "panel POTRF + TRSM + trailing SYRK": the same matrix in TRSM mode (R only, no inverse formed)
         r2t = time_cholesky(driver, L, h, n2, 1, bc_mult_for(n2, 1, 1, BASE_CASE_ORDER), 0, max(args.steps, 3), 1, False, device, bc_policy=2, trsm_mode=True)
         out["config2"]["trsm_mode"] = {"tflops": r2t["tflops"], "ms_per_step": r2t["ms_per_step"], "residual": r2t["residual"]}

@@ -212,9 +212,14 @@ int capi_stream_select(capi_handle_t h, int which) {
 // stream of a grid run -- find no slot before a resident round ends (stream priorities only order the dispatcher's choices, they free
 // nothing).  With a CU mask on the compute stream those kernels start at once, on CUs the tile kernel never touches; the tile launches
 // count their rounds on the remaining CUs (cu_of).  Mask bit b is CU b / 8 of XCD b % 8: the reserve is spread evenly over the XCDs.
-// Only for handles that own their compute stream; drains the handle's streams.
+// Only for handles that own their compute stream; drains the handle's streams.  NOT applied by default: measured on the chunked trailing update of
+// config 4's top level, a kernel of the communication stream starts one resident round (3.7 ms at K = 16384) after its event without a reserve and
+// 10 us after it with one -- but 32 reserved CUs cost the update 12.5 % (81.0 against 73.1 ms pipelined): the lag is cheaper than the cure.
 int capi_reserve_cus(capi_handle_t h, int reserve) {
-  CAPI_REQUIRE(h, h && reserve >= 0 && reserve < h->num_cu && reserve % 8 == 0, "reserve: a multiple of 8 below the CU count");
+  // (multiples of 32 only: one CU per shader engine per XCD.  The dispatcher deals a launch's workgroups evenly over the four shader engines of
+  //  an XCD; with unequal engines the short one takes a second pass while the others idle -- measured: 8 reserved CUs cost 65 % of the tile
+  //  kernel's rate, 16 cost 40 %, 32 the proportional 12.5 %; profiles/r4_overlap_contention.txt)
+  CAPI_REQUIRE(h, h && reserve >= 0 && reserve < h->num_cu && reserve % 32 == 0, "reserve: a multiple of 32 below the CU count");
   CAPI_REQUIRE(h, h->owns_stream, "the compute stream belongs to the caller");
   CAPI_HIP_CHECK(h, hipSetDevice(h->device));
   int rc = capi_sync(h);

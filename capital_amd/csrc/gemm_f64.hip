@@ -1774,7 +1774,11 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
   // A 128-tiling fills the chip in rounds of 2 x CUs workgroups; the last round is usually partial and its lone
   // workgroups run at ~0.6 of the paired rate (8256 tiles = 16 rounds + 64: those 64 cost almost another round).  The
   // tail is re-cut into 64-tiles (4x the workgroups, a quarter of the length) and launched right behind the full rounds.
-  const int rounds_mode = h->rounds_mode;
+  // (CAPI_ROUNDS_MIN_K: products shallower than this keep the handle's environment defaults -- one launch, pairs up to four whole rounds --
+  //  even while capi_set_launch_rounds is on: a round of a shallow product is short, and every boundary drains the chip once; A/B knob)
+  static const int rounds_min_k = getenv("CAPI_ROUNDS_MIN_K") ? atoi(getenv("CAPI_ROUNDS_MIN_K")) : 0;
+  const bool deep = p.K >= rounds_min_k;
+  const int rounds_mode = deep ? h->rounds_mode : h->rounds_env[0];
   const int64_t per_round = 2 * (int64_t)(h->cu_of[h->cur] ? h->cu_of[h->cur] : h->num_cu);
   // (bit 0: plain products; bit 1: triangular outputs in the banded order -- an XCD's 64 tiles of a round are an 8 x 8 block of the triangle)
   // (the 256-column block launches of a tall right-TRMM were tried the same way: a round there is 512 tiles of K <= 1024, ~0.15 ms, and the
@@ -1838,7 +1842,7 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
   // bulk stream queue behind the chain's kernels at every boundary (0.876 -> 0.825 on the same box).
   // TRMM in tile pairs (dtrmm_pair_kernel): equal work per workgroup, the launch of a plain product
   {
-    const int pair_mode = h->pair_mode;
+    const int pair_mode = deep ? h->pair_mode : h->rounds_env[1];
     // Measured (tools/pair_window.py, all three forms of the recursion): a launch of exactly one resident round +8..10 % (order 4096:
     // 63 -> 68.5 TFLOP/s; 2048 x 8192: 51..55 -> 55..59), two rounds +2..3 %, four +0.5..1 %, nine +-0.5 %; a launch that is NOT whole
     // rounds loses (1152 workgroups, order 6144: 68.3 -> 61.5 -- the equal, long workgroups of the last 128 cost a third round).
@@ -1846,7 +1850,7 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
     // (CAPI_TRMM_PAIR=2: whenever the launch is whole rounds; =0: never); larger products keep the longest-first order.
     const int ntri_ = p.tri_side == CAPI_LEFT ? p.tiles_m : p.tiles_n, nfree_ = p.tri_side == CAPI_LEFT ? p.tiles_n : p.tiles_m;
     const int64_t wgs = (int64_t)(ntri_ / 2) * nfree_;
-    const int pair_rounds = h->pair_rounds, pair_rounds_min = h->pair_rounds_min;
+    const int pair_rounds = deep ? h->pair_rounds : h->rounds_env[2], pair_rounds_min = deep ? h->pair_rounds_min : h->rounds_env[3];
     if (pair_mode && tri && !p.tri_dense && !p.tri_block && p.tri_koff == 0 && p.ts == 128 && p.splitk == 1 && p.beta == 0.0 && p.batch <= 1 &&
         p.M % 128 == 0 && p.N % 128 == 0 && p.K % 128 == 0 && p.a_vec && p.b_vec && (ntri_ & 1) == 0 &&
         wgs % per_round == 0 && (pair_mode > 1 || wgs <= 4 * per_round || (pair_rounds && p.K >= pair_rounds_min))) {
@@ -2037,6 +2041,10 @@ static int trmm_launch(capi_handle_t h, int side, int uplo, int trans, int diag,
     //  B_J read once -- and the part above it as a dense beta = 1 product on the tile kernel: 16.25 instead of 18 executed units of
     //  m * 65536 flops at n = 1024, yet 36.1 against 35.3 ms at m = 2^21 (n = 512: 10.4 against 9.8): the accumulating products have
     //  K = 256 .. 768 only, and a 128-tile with 16-48 iterations spends too much of its life in prologue, C read and epilogue.)
+    // (Round 4, measured and dropped: FAST iterations over the eight panels that cross T's diagonal with the wave's dead sub-tile COLUMNS left out
+    //  (44 % of those panels' MFMAs, wave-uniform branches, no masking needed on the clean copy): 141.4 / 141.9 against 141.4 / 141.7 ms at
+    //  m = 2^23, n = 1024 -- nothing.  A panel costs what its busiest wave costs: the waves of the tile's right half keep all their columns until
+    //  the last three panels, and the barrier makes the others wait for them.  profiles/r4_tall_trmm_band_skip_ab.txt.)
     if (!one_launch && eff_upper && n % 256 == 0) {
       for (int64_t J = 0; J < n / 256; ++J) {
         GemmArgs q = p;
@@ -2149,6 +2157,17 @@ int capi_dtrmm_right_panel32(capi_handle_t h, int64_t m, int64_t n, double alpha
   return launch_gemm(h, false, true, p, true);
 }
 
+// which recorded launches a `variant` code of capi_prof_collect[_intervals] selects.  A record's variant is (transposed-A ? 2 : 0) +
+// (k-contiguous B ? 1 : 0) [+ 4: the 64-tile kernel] [+ 16: dtrmm_pair_kernel, the 128-tile kernel's form for TRMMs in tile pairs].
+//   -1: every record;  0..3: that operand orientation, any kernel;  8 + v: exactly record variant v (one kernel symbol);
+//   100 + o: the 128-tile kernels of orientation o -- dgemm_tile_kernel<128, ..> and dtrmm_pair_kernel<..> (two symbols, one inner loop)
+static bool prof_selected(int code, int rec) {
+  if (code < 0) return true;
+  if (code >= 100) return rec == code - 100 || rec == 16 + (code - 100);
+  if (code >= 8) return rec == code - 8;
+  return (rec & 3) == code;
+}
+
 int capi_prof_enable(capi_handle_t h, int on) {
   CAPI_REQUIRE(h, h, "null handle");
   h->prof_on = on != 0;
@@ -2193,7 +2212,7 @@ int capi_prof_collect_intervals(capi_handle_t h, int variant, int64_t* launches,
   const double ms_per_tick = 1.0 / (double)h->wall_khz;
   static const bool dump = getenv("CAPI_PROF_DUMP") != nullptr;
   for (int i = 0; i < n; ++i) {
-    if (variant >= 8 ? h->prof[i].variant != variant - 8 : (variant >= 0 && (h->prof[i].variant & 3) != variant)) continue;
+    if (!prof_selected(variant, h->prof[i].variant)) continue;
     const unsigned long long a = st[2 * i], b = ~st[2 * i + 1];
     if (st[2 * i] == ~0ull || st[2 * i + 1] == ~0ull || b < a) continue;       // (a launch without workgroups, or not yet run)
     v[m++] = {a, b};
@@ -2225,7 +2244,7 @@ int capi_prof_collect(capi_handle_t h, int variant, int64_t* launches, double* t
   if (max_ms) *max_ms = 0;
   for (int i = 0; i < h->prof_n; ++i) {
     // 0..3: operand orientations, any tile size;  8 + v: exactly variant v (bit 2 set = 64-tile kernel)
-    if (variant >= 8 ? h->prof[i].variant != variant - 8 : (variant >= 0 && (h->prof[i].variant & 3) != variant)) continue;
+    if (!prof_selected(variant, h->prof[i].variant)) continue;
     float ms = 0;
     CAPI_HIP_CHECK(h, hipEventElapsedTime(&ms, h->prof[i].e0, h->prof[i].e1));
     *launches += 1; *total_ms += ms; *total_flops += h->prof[i].flops;

@@ -65,7 +65,7 @@ int  capi_trim_workspaces(capi_handle_t h);
  * all run on one stream (grids, the TRSM mode); on = 0: the handle's defaults (environment: CAPI_ROUNDS, CAPI_TRMM_PAIR, CAPI_TRMM_PAIR_ROUNDS).
  * *was (may be NULL) receives the previous setting. */
 int  capi_set_launch_rounds(capi_handle_t h, int on, int* was);
-/* keep the handle's compute stream off `reserve` CUs (a multiple of 8; 0 = all CUs again): the communication stream's kernels (RCCL's
+/* keep the handle's compute stream off `reserve` CUs (a multiple of 32: one per shader engine and XCD; 0 = all CUs again): the communication stream's kernels (RCCL's
  * send/recv on a grid) then start at once beside a tile launch instead of at its next round boundary.  Drains the handle's streams. */
 int  capi_reserve_cus(capi_handle_t h, int reserve);
 
@@ -217,7 +217,8 @@ int capi_mfma_f64_peak(capi_handle_t h, int iters, double* tflops);
  * enable, run the workload, collect = number of launches, summed duration and summed algorithmic flops of one
  * kernel variant (0..3 = operand orientations at any tile size, 3 = both operands k-contiguous, the TN kernel of the
  * trailing update; 8 + v = exactly variant v, where bit 2 of v marks the 64-tile kernel: 11 = the 128-tile TN kernel
- * alone, i.e. one kernel symbol; -1 = all variants). */
+ * alone, i.e. one kernel symbol; 8 + 16 + v = dtrmm_pair_kernel (the 128-tile kernel's form for TRMMs in tile pairs) of orientation v; 100 + o = both 128-tile symbols of operand
+ * orientation o; -1 = all variants). */
 int capi_prof_enable(capi_handle_t h, int on);
 int capi_prof_collect(capi_handle_t h, int variant, int64_t* launches, double* total_ms, double* total_flops, double* max_ms);
 /* the same records timed by the kernels themselves (first workgroup's start .. last workgroup's end, wall-clock ticks): *union_ms = length

@@ -5,6 +5,7 @@
 #include "capi_internal.h"
 
 static void graphs_invalidate(capi_handle_t h);
+extern "C" int capi_internal_copy2d(capi_handle_t h, int64_t m, int64_t n, const double* A, int64_t lda, double* B, int64_t ldb);   // movement.hip
 
 extern "C" {
 
@@ -140,7 +141,10 @@ int capi_memcpy_d2h(capi_handle_t h, void* d, const void* s, size_t bytes) {
 }
 int capi_memcpy_d2d_async(capi_handle_t h, void* d, const void* s, size_t bytes) {
   CAPI_REQUIRE(h, h, "null handle");
-  if (bytes) CAPI_HIP_CHECK(h, hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, h->stream));
+  if (!bytes) return CAPI_OK;
+  // whole doubles on 8-byte boundaries (every caller in the host layer): the product's own copy kernel (movement.hip), see there
+  if ((bytes & 7) == 0 && ((((uintptr_t)d) | ((uintptr_t)s)) & 7) == 0) return capi_internal_copy2d(h, (int64_t)(bytes / 8), 1, (const double*)s, (int64_t)(bytes / 8), (double*)d, (int64_t)(bytes / 8));
+  CAPI_HIP_CHECK(h, hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, h->stream));
   return CAPI_OK;
 }
 int capi_sync(capi_handle_t h) {

@@ -29,6 +29,8 @@
 #include "capi_internal.h"
 #include <type_traits>
 
+extern "C" int capi_internal_copy2d(capi_handle_t h, int64_t m, int64_t n, const double* A, int64_t lda, double* B, int64_t ldb);   // movement.hip
+
 typedef double d4_t __attribute__((ext_vector_type(4)));
 typedef double d2_t __attribute__((ext_vector_type(2)));
 
@@ -2119,9 +2121,7 @@ int capi_dtrmm(capi_handle_t h, int side, int uplo, int trans, int diag, int64_t
   if (rc != CAPI_OK) return rc;
   rc = trmm_launch(h, side, uplo, trans, diag, m, n, alpha, T, ldt, B, ldb, 0.0, (double*)ws, m, /*ws_free=*/false);
   if (rc != CAPI_OK) return rc;
-  CAPI_HIP_CHECK(h, hipMemcpy2DAsync(B, sizeof(double) * ldb, ws, sizeof(double) * m, sizeof(double) * m, n,
-                                     hipMemcpyDeviceToDevice, h->stream));
-  return CAPI_OK;
+  return capi_internal_copy2d(h, m, n, (const double*)ws, m, B, ldb);
 }
 
 // ---- "panel32" images of a tall panel (CholeskyQR2, n = 256) -------------------------------------------------------------------------------

@@ -61,6 +61,36 @@ __global__ void lacpy_kernel(int part, int64_t m, int64_t n, const double* __res
   }
 }
 
+// Whole m x n block, B <- A: the product's own copy kernel (round 4) instead of hipMemcpy2DAsync.  Every thread moves the same row pair of
+// eight consecutive columns, the eight 16-byte loads in flight before the first store; column groups are walked grid-stride in y.
+// Why not the runtime's copy: hipMemcpy2DAsync / hipMemcpyAsync device-to-device are blit kernels that the HIP runtime dispatches on its own
+// (4000 of them per bench process, nearly all behind the in-place TRMMs of the TRSM mode).  With its own kernel every dispatch the product
+// makes is a plain kernel launch -- one code path through the runtime and through a profiler's queue interception (profiles/README.md: the
+// host SIGSEGV of `rocprofv3 --pmc` sits in librocprofiler-sdk's packet interceptor) -- and the small copies lose the blit path's set-up cost.
+typedef double d2m_t __attribute__((ext_vector_type(2)));
+template <bool VEC>
+__global__ __launch_bounds__(256) void copy2d_kernel(int64_t m, int64_t n, const double* __restrict__ A, int64_t lda, double* __restrict__ B, int64_t ldb) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * (VEC ? 2 : 1);
+  if (i >= m) return;
+  for (int64_t j0 = (int64_t)blockIdx.y * 8; j0 < n; j0 += (int64_t)gridDim.y * 8) {
+    if (VEC) {
+      d2m_t v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = *(const d2m_t*)(A + i + (j0 + q < n ? j0 + q : j0) * lda);
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (j0 + q < n) *(d2m_t*)(B + i + (j0 + q) * ldb) = v[q];
+    } else {
+      double v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = A[i + (j0 + q < n ? j0 + q : j0) * lda];
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (j0 + q < n) B[i + (j0 + q) * ldb] = v[q];
+    }
+  }
+}
+
 // Y(part) <- alpha*X + beta*Y on an m x n block (summa.hpp:33,153 generalised to strided blocks)
 __global__ void geadd_kernel(int part, int64_t m, int64_t n, double alpha, const double* __restrict__ X, int64_t ldx, double beta,
                              double* __restrict__ Y, int64_t ldy) {
@@ -279,16 +309,37 @@ int capi_serialize(capi_handle_t h, int ss, int ds, const double* src, int64_t s
   return capi_serialize_shape(h, shape, ss, ds, src, sdimX, sdimY, dst, ddimX, ddimY, ssx, sex, ssy, sey, dsx, dex, dsy, dey);
 }
 
+// B(m x n, ldb) <- A(m x n, lda) on the handle's stream (the blocks may not overlap unless they coincide)
+__attribute__((visibility("hidden"))) int capi_internal_copy2d(capi_handle_t h, int64_t m, int64_t n, const double* A, int64_t lda, double* B, int64_t ldb) {
+  if (m <= 0 || n <= 0 || (A == B && lda == ldb)) return CAPI_OK;
+  static const bool runtime_copy = getenv("CAPI_RUNTIME_COPY") != nullptr;      // A/B: the HIP runtime's blit kernels, as before round 4
+  if (runtime_copy) {
+    CAPI_HIP_CHECK(h, hipMemcpy2DAsync(B, sizeof(double) * ldb, A, sizeof(double) * lda, sizeof(double) * m, n, hipMemcpyDeviceToDevice, h->stream));
+    return CAPI_OK;
+  }
+  if (lda == m && ldb == m && m * n >= (1 << 16) && (m > 8192 || n == 1)) {
+    // contiguous on both sides: re-cut into columns of 8192 (eight 16-byte pieces in flight per thread), the rest as a short column behind them
+    const int64_t total = m * n, cols = total / 8192, rest = total - cols * 8192;
+    int rc = capi_internal_copy2d(h, 8192, cols, A, 8192, B, 8192);
+    if (rc != CAPI_OK || rest == 0) return rc;
+    return capi_internal_copy2d(h, rest, 1, A + cols * 8192, rest, B + cols * 8192, rest);
+  }
+  const bool vec = (((uintptr_t)A | (uintptr_t)B) & 15) == 0 && ((lda | ldb | m) & 1) == 0;
+  const int64_t gx = cdiv(vec ? m / 2 : m, 256), gy = cdiv(n, 8);
+  CAPI_REQUIRE(h, gx < (1LL << 31), "copy too tall");
+  const dim3 grid((unsigned)gx, (unsigned)(gy < 65535 ? gy : 65535));
+  if (vec) hipLaunchKernelGGL(copy2d_kernel<true>, grid, dim3(256), 0, h->stream, m, n, A, lda, B, ldb);
+  else hipLaunchKernelGGL(copy2d_kernel<false>, grid, dim3(256), 0, h->stream, m, n, A, lda, B, ldb);
+  CAPI_HIP_CHECK(h, hipGetLastError());
+  return CAPI_OK;
+}
+
 int capi_dlacpy(capi_handle_t h, int part, int64_t m, int64_t n, const double* A, int64_t lda, double* B, int64_t ldb) {
   CAPI_REQUIRE(h, h, "null handle");
   CAPI_REQUIRE(h, part >= 0 && part <= 2 && m >= 0 && n >= 0, "args");
   if (m == 0 || n == 0) return CAPI_OK;
   CAPI_REQUIRE(h, A && B && lda >= m && ldb >= m, "operands");
-  if (part == 0) {
-    CAPI_HIP_CHECK(h, hipMemcpy2DAsync(B, sizeof(double) * ldb, A, sizeof(double) * lda, sizeof(double) * m, n,
-                                       hipMemcpyDeviceToDevice, h->stream));
-    return CAPI_OK;
-  }
+  if (part == 0) return capi_internal_copy2d(h, m, n, A, lda, B, ldb);
   const int64_t gy = cdiv(n, 8);
   CAPI_REQUIRE(h, gy <= 65535, "n too large");
   hipLaunchKernelGGL(lacpy_kernel, dim3((unsigned)cdiv(m, 256), (unsigned)gy), dim3(256), 0, h->stream, part, m, n, A, lda, B, ldb);

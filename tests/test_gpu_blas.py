@@ -541,3 +541,89 @@ def test_launches_in_resident_rounds_give_the_same_products(hip):
     assert (base[2] - rounds[2]).abs().max().item() <= 1e-13 * scale
     ref = (torch.triu(T.T).T @ B.T).T                               # column-major: Ct = T^T B
     assert (rounds[2] - ref).abs().max().item() <= 1e-12 * scale
+
+
+@pytest.mark.gpu
+def test_interval_stamps_of_the_tile_kernels(hip):
+    """capi_prof_collect_intervals (round 4): every recorded launch of the tile kernels stamps its own execution interval.  Launches of ONE stream
+    run back to back: the union of the intervals equals their sum to within dispatch gaps and stays inside the HIP-event bracket of the whole
+    sequence; a product launched in resident rounds records one interval per round, with the same flops in total; variant 100 + o selects both
+    128-tile symbols of an orientation (dgemm_tile_kernel and dtrmm_pair_kernel), 8 + v exactly one."""
+    import ctypes as C
+    import torch
+    from capital_amd import capi
+    L = capi.load()
+    n = 8192
+    torch.manual_seed(7)
+    A = torch.rand((n, n), dtype=torch.float64, device="cuda") - 0.5
+    T = torch.triu(torch.rand((n, n), dtype=torch.float64, device="cuda") - 0.5).T.contiguous()
+    Cs = torch.zeros((n, n), dtype=torch.float64, device="cuda")
+    Ct = torch.zeros((n, n), dtype=torch.float64, device="cuda")
+
+    def collect(code):
+        v = [C.c_int64(), C.c_double(), C.c_double(), C.c_double(), C.c_double()]
+        assert L.capi_prof_collect_intervals(hip.h, code, C.byref(v[0]), C.byref(v[1]), C.byref(v[2]), C.byref(v[3]), C.byref(v[4])) == 0
+        return v[0].value, v[1].value, v[2].value, v[3].value, v[4].value
+
+    def run(rounds):
+        assert L.capi_set_launch_rounds(hip.h, rounds, None) == 0
+        try:
+            hip.call("capi_dsyrk", 1, 1, n, n, -1.0, capi.ptr(A), n, 0.0, capi.ptr(Cs), n)           # warm-up (workspaces, LDS limits)
+            hip.call("capi_dtrmm_oop", 0, 1, 1, 0, n, n, 1.0, capi.ptr(T), n, capi.ptr(A), n, capi.ptr(Ct), n)
+            hip.sync()
+            assert L.capi_prof_enable(hip.h, 1) == 0
+            ms = C.c_float()
+            hip.call("capi_timer_start")
+            hip.call("capi_dsyrk", 1, 1, n, n, -1.0, capi.ptr(A), n, 0.0, capi.ptr(Cs), n)           # TN, triangular output
+            hip.call("capi_dtrmm_oop", 0, 1, 1, 0, n, n, 1.0, capi.ptr(T), n, capi.ptr(A), n, capi.ptr(Ct), n)   # left, upper, transposed: TN
+            hip.call("capi_timer_stop_ms", C.byref(ms))
+            assert L.capi_prof_enable(hip.h, 0) == 0
+            return ms.value, collect(103), collect(11), collect(27), collect(-1)
+        finally:
+            assert L.capi_set_launch_rounds(hip.h, 0, None) == 0
+
+    flops = float(n) * (n + 1.0) * n + float(n) * n * n                     # syrk N (N + 1) K + trmm M^2 N
+    for rounds in (0, 1):
+        total_ms, both, tile, pair, every = run(rounds)
+        launches, union, ssum, fl, mx = both
+        # (the 32 tiles of the triangle's partial last round are re-cut into 64-tiles: that launch is in neither the record's flops nor its interval)
+        assert flops * (1 - 32.0 / 2080 * 0.51) - 1e-3 * flops <= fl <= flops * (1 + 1e-12), (rounds, fl, flops)
+        assert tile[0] + pair[0] == launches and launches >= (2 if rounds == 0 else 8)
+        assert 0.0 < union <= ssum * (1 + 1e-9) and mx <= union * (1 + 1e-9)
+        assert union <= total_ms * 1.02 and ssum >= 0.85 * total_ms, (rounds, union, ssum, total_ms)      # one stream: back to back, inside the bracket
+        assert every[3] >= fl
+        assert 40.0 < fl / (union * 1e-3) / 1e12 < 78.6                       # a rate a tile kernel can have
+
+
+@pytest.mark.gpu
+def test_reserved_cus_leave_the_products_unchanged(hip):
+    """capi_reserve_cus: the compute stream under a CU mask (round 4: what a caller with latency-critical transfers can turn on so that kernels of
+    the communication stream start at once beside a tile launch).  Multiples of 32 only (one CU per shader engine and XCD: anything else leaves
+    the engines of an XCD unequal and costs up to 65 % of the tile kernel's rate, profiles/r4_overlap_contention.txt); same bits with and without;
+    a borrowed stream cannot be masked.  Own handle: the session's would keep the mask."""
+    import ctypes as C
+    import torch
+    from capital_amd import capi
+    L = capi.load()
+    assert L.capi_reserve_cus(hip.h, 32) != 0                   # the session's handle borrows torch's stream
+    hnd = capi.Handle(0, own_stream=True)
+    try:
+        n = 4096
+        torch.manual_seed(3)
+        A = torch.rand((n, n), dtype=torch.float64, device="cuda") - 0.5
+        torch.cuda.synchronize()                                 # (the handle's own stream is not torch's)
+        out = []
+        for reserve in (0, 32, 64, 0):
+            assert L.capi_reserve_cus(hnd.h, reserve) == 0
+            Cc = torch.zeros((n, n), dtype=torch.float64, device="cuda")
+            torch.cuda.synchronize()
+            assert L.capi_set_launch_rounds(hnd.h, 1, None) == 0
+            hnd.call("capi_dgemm", 1, 0, n, n, n, 1.0, capi.ptr(A), n, capi.ptr(A), n, 0.0, capi.ptr(Cc), n)
+            hnd.call("capi_dsyrk", 1, 1, n, n, -1.0, capi.ptr(A), n, 1.0, capi.ptr(Cc), n)
+            hnd.sync()
+            out.append(Cc)
+        for o in out[1:]:
+            assert torch.equal(out[0], o)
+        assert L.capi_reserve_cus(hnd.h, 8) != 0 and L.capi_reserve_cus(hnd.h, -32) != 0 and L.capi_reserve_cus(hnd.h, 256) != 0
+    finally:
+        hnd.close()

@@ -210,3 +210,30 @@ def test_cyclic_to_local(hip, oracle, L, d):
         got, goti = dT.cpu().numpy().reshape(bc, bc), dTI.cpu().numpy().reshape(bc, bc)
         np.testing.assert_array_equal(got[:L, :L], rT.reshape(bc, bc)[:L, :L])           # the leading corner (column index first)
         np.testing.assert_array_equal(goti[:L, :L], rTI.reshape(bc, bc)[:L, :L])
+
+
+@pytest.mark.parametrize("m,n,lda,ldb,off", [(1, 1, 1, 1, 0), (7, 5, 9, 11, 0), (512, 8, 512, 512, 0), (513, 9, 513, 514, 0), (1024, 33, 1030, 1026, 1),
+                                             (8192, 8, 8192, 8192, 0), (8192, 9, 8192, 8192, 0), (100003, 3, 100003, 100003, 0), (4096, 70001 // 4096 + 1, 4096, 4100, 0)])
+def test_own_copy_kernel_bit_exact(hip, m, n, lda, ldb, off):
+    """capi_dlacpy(part 0) and capi_memcpy_d2d_async run on the product's own copy kernel (round 4; no hipMemcpy2DAsync / hipMemcpyAsync blits):
+    ragged heights, odd leading dimensions, an operand 8 bytes off a 16-byte boundary, contiguous blocks re-cut into 8192-columns with a rest.
+    Everything outside the destination block must stay untouched."""
+    import torch
+    from capital_amd import capi
+    torch.manual_seed(m * 31 + n)
+    A = torch.rand(lda * n + off + 4, dtype=torch.float64, device="cuda")
+    B = torch.full((ldb * n + off + 4,), -7.0, dtype=torch.float64, device="cuda")
+    hip.call("capi_dlacpy", 0, m, n, capi.ptr(A) + 8 * off, lda, capi.ptr(B) + 8 * off, ldb)
+    hip.sync()
+    ref = torch.full_like(B, -7.0)
+    Av = A[off:off + lda * n].view(n, lda)
+    ref[off:off + ldb * n].view(n, ldb)[:, :m] = Av[:, :m]
+    assert torch.equal(B, ref)
+    # the contiguous 1-D form
+    cnt = lda * n
+    D = torch.full((cnt + 6,), 3.0, dtype=torch.float64, device="cuda")
+    hip.call("capi_memcpy_d2d_async", capi.ptr(D) + 8 * (1 + off), capi.ptr(A) + 8 * off, 8 * cnt)
+    hip.sync()
+    ref = torch.full_like(D, 3.0)
+    ref[1 + off:1 + off + cnt] = A[off:off + cnt]
+    assert torch.equal(D, ref)

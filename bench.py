@@ -33,6 +33,15 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# Under rocprofv3 a long process must not let a HIP queue's ring wrap: with `--pmc`, librocprofiler-sdk's packet interceptor (ROCm 7.2.0) reads
+# past the END of the 1 MiB ring (16384 AQL packets) when the HSA runtime hands it a batch that crosses the wrap -- a host SIGSEGV late in the
+# process, located in round 4 (profiles/r4_pmc_whole_bench_crash.txt; rounds 2-3 recorded it as rc 139).  A ring of 131072 packets never wraps
+# within a bench process (~50 000 dispatches); set before the HIP runtime creates its queues, and only when a profiler is attached.
+if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+    if "ROC_AQL_QUEUE_SIZE" not in os.environ:
+        os.environ["ROC_AQL_QUEUE_SIZE"] = "131072"
+        sys.stderr.write("bench.py: a rocprofiler tool is attached: ROC_AQL_QUEUE_SIZE=131072 (see profiles/r4_pmc_whole_bench_crash.txt)\n")
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 

@@ -8,9 +8,8 @@
 #   4  PMC pass of the TRSM-mode leg in a process of its own
 #   5  PMC passes of the tall-skinny kernels: n = 256 (column-major and panel32 forms) and n = 1024 (config 5's width)
 #   6  kernel trace of two n = 32768 steps: idle analysis of config 2
-#   7  ONE recorded attempt of the whole bench process under --pmc (rounds 2 and 3: host SIGSEGV late in the process).  This time the WHOLE stderr
-#      is kept, the process writes its /proc/self/maps at every leg (CAPITAL_BENCH_DUMP_MAPS), and whatever the profiler left on disk is listed:
-#      the two unnamed frames above the launch stub can be attributed to a module from the addresses alone.
+#   7  the whole bench process (config 2 and both TRSM legs included) under --pmc: rounds 2 and 3 recorded a host SIGSEGV here; located in round 4
+#      (a queue-ring wrap inside the profiler's packet interceptor, r4_pmc_whole_bench_crash.txt) and avoided by a ring that never wraps: required to pass
 set -o pipefail
 export TMPDIR=/tmp
 O=gpurun_out/cap4
@@ -92,12 +91,19 @@ timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $O/tr2 -o b --
 if [ $rc -eq 0 ]; then python tools/gap_analysis.py $(find $O/tr2 -name "b_kernel_trace.csv" | head -1) 3 > $O/gaps_n32768.txt 2>&1; rc=$?; fi
 rm -rf $O/tr2; leg 6-gaps-n32768 $rc
 
-# the crash case of rounds 2 and 3, once: the whole bench process (config 2 and both TRSM legs included) under --pmc.  RECORDED, not required.
-CAPITAL_BENCH_DUMP_MAPS=$O/pmc_whole_maps.txt timeout -k 10 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_whole -o p -- python bench.py --steps 1 --warmup 0 --no-cpu --no-qr > $O/pmc_whole.json 2> $O/pmc_whole.err; rc=$?
-echo "leg 7-whole-bench-under-pmc rc=$rc (recorded only)" | tee -a $O/legs.txt
-{ echo "# files the profiler left behind (rows = dispatches recorded so far):"; find $O/pmc_whole -type f -exec wc -l {} + 2>/dev/null; } > $O/pmc_whole_files.txt
-rm -rf $O/pmc_whole
-if [ $rc -eq 0 ]; then rm -f $O/pmc_whole_maps.txt; else { head -1 $O/pmc_whole_maps.txt; grep "r-xp" $O/pmc_whole_maps.txt | awk '{print $1, $3, $6}'; } > $O/pmc_whole_maps_modules.txt; rm -f $O/pmc_whole_maps.txt; fi
+# The crash case of rounds 2 and 3 (host SIGSEGV of the whole bench process under --pmc), located and resolved in round 4
+# (profiles/r4_pmc_whole_bench_crash.txt: the profiler's packet interceptor reads past the end of a 16384-packet queue ring; bench.py now asks for a ring
+# that never wraps whenever a rocprofiler tool is attached).  REQUIRED to pass from now on.
+timeout -k 10 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_whole -o p -- python bench.py --steps 1 --warmup 0 --no-cpu --no-qr > $O/pmc_whole.json 2> $O/pmc_whole.err; rc=$?
+if [ $rc -eq 0 ]; then python - > $O/pmc_whole_dispatches.txt <<PY
+import csv, collections
+f = "$(find $O/pmc_whole -name 'p_counter_collection.csv' | head -1)"
+cnt = collections.Counter(r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][-60:] for r in csv.DictReader(open(f)))
+print("whole bench process under rocprofv3 --pmc FETCH_SIZE: dispatches profiled:", sum(cnt.values()))
+for k, v in cnt.most_common(16): print("  ", v, k)
+PY
+else tail -60 $O/pmc_whole.err > $O/pmc_whole_tail.err; fi
+rm -rf $O/pmc_whole $O/pmc_whole.err; leg 7-whole-bench-under-pmc $rc
 
 ls -la $O; cat $O/legs.txt; cat $O/timed_region.txt; cut -c1-400 $O/bench.json
 exit $fail

@@ -5,6 +5,20 @@
 #include "capi_internal.h"
 
 static void graphs_invalidate(capi_handle_t h);
+
+hipError_t capi_release(capi_handle_t h, void* p) {
+  static const bool defer = getenv("CAPI_DEFER_FREE") != nullptr;
+  if (!p) return hipSuccess;
+  if (!defer || !h) return hipFree(p);
+  if (h->deferred_n == h->deferred_cap) {
+    const int ncap = h->deferred_cap ? 2 * h->deferred_cap : 64;
+    void** np_ = (void**)realloc(h->deferred, sizeof(void*) * ncap);
+    if (!np_) return hipFree(p);
+    h->deferred = np_; h->deferred_cap = ncap;
+  }
+  h->deferred[h->deferred_n++] = p;
+  return hipSuccess;
+}
 extern "C" int capi_internal_copy2d(capi_handle_t h, int64_t m, int64_t n, const double* A, int64_t lda, double* B, int64_t ldb);   // movement.hip
 
 extern "C" {
@@ -96,6 +110,8 @@ int capi_destroy(capi_handle_t h) {
   for (int i = 0; i < h->prof_cap; ++i) if (h->prof[i].e0) { (void)hipEventDestroy(h->prof[i].e0); (void)hipEventDestroy(h->prof[i].e1); }
   free(h->prof);
   if (h->d_stamps) (void)hipFree(h->d_stamps);
+  for (int i = 0; i < h->deferred_n; ++i) (void)hipFree(h->deferred[i]);
+  free(h->deferred);
   for (int i = 0; i < h->graphs_n; ++i) if (h->graphs[i].exec) (void)hipGraphExecDestroy(h->graphs[i].exec);
   free(h->graphs);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -117,7 +133,7 @@ int capi_malloc(capi_handle_t h, void** p, size_t bytes) {
 }
 int capi_free(capi_handle_t h, void* p) {
   CAPI_REQUIRE(h, h, "null handle");
-  if (p) { CAPI_HIP_CHECK(h, hipStreamSynchronize(h->stream)); CAPI_HIP_CHECK(h, hipFree(p)); }
+  if (p) { CAPI_HIP_CHECK(h, hipStreamSynchronize(h->stream)); CAPI_HIP_CHECK(h, capi_release(h, p)); }
   return CAPI_OK;
 }
 int capi_memset_async(capi_handle_t h, void* p, int v, size_t bytes) {
@@ -345,7 +361,7 @@ static int ws_grow(capi_handle_t h, void** slot, size_t* cap, size_t bytes, void
       if (h->streams[i] && h->streams[i] != h->stream) CAPI_HIP_CHECK(h, hipStreamSynchronize(h->streams[i]));
     CAPI_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     graphs_invalidate(h);
-    if (*slot) CAPI_HIP_CHECK(h, hipFree(*slot));
+    if (*slot) CAPI_HIP_CHECK(h, capi_release(h, *slot));
     *slot = nullptr;
     *cap = 0;
     size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
@@ -382,7 +398,7 @@ extern "C" int capi_trim_workspaces(capi_handle_t h) {
     void** blocks[4] = {&h->ws[i], &h->ws2[i], &h->ws3[i], &h->ws4[i]};
     size_t* sizes[4] = {&h->ws_bytes[i], &h->ws2_bytes[i], &h->ws3_bytes[i], &h->ws4_bytes[i]};
     for (int b = 0; b < 4; ++b)
-      if (*blocks[b]) { CAPI_HIP_CHECK(h, hipFree(*blocks[b])); *blocks[b] = nullptr; *sizes[b] = 0; }
+      if (*blocks[b]) { CAPI_HIP_CHECK(h, capi_release(h, *blocks[b])); *blocks[b] = nullptr; *sizes[b] = 0; }
   }
   return CAPI_OK;
 }

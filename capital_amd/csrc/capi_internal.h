@@ -45,6 +45,11 @@ struct capi_handle_s {
   unsigned long long* d_stamps = nullptr;
   int stamps_cap = 0;
   int wall_khz = 100000;          // rate of wall_clock64() (hipDeviceAttributeWallClockRate)
+  // CAPI_DEFER_FREE: blocks whose release is put off until capi_destroy.  hipFree drains the WHOLE device; with several handles of one process on
+  // one GPU whose streams wait for each other's messages on the device (ranks as threads over the asynchronous loopback transport) that wait can
+  // never end.  Off by default: one rank per process frees at once.
+  void** deferred = nullptr;
+  int deferred_n = 0, deferred_cap = 0;
   // kernels whose dynamic-LDS limit has been raised on THIS handle's device (hipFuncSetAttribute is per device; a
   // process-wide flag would leave a second device's copy of the kernel at the default limit)
   uint32_t lds_attr_done = 0;
@@ -94,3 +99,6 @@ int capi_ws3_get(capi_handle_t h, size_t bytes, void** p);
 int capi_ws4_get(capi_handle_t h, size_t bytes, void** p);
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// hipFree, or (CAPI_DEFER_FREE) remember the block until capi_destroy
+hipError_t capi_release(capi_handle_t h, void* p);

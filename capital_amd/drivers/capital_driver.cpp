@@ -11,7 +11,7 @@
 
 namespace {
 
-std::string g_err;
+CAPITAL_RANK_LOCAL std::string g_err;      // (per rank: thread-local in the ranks-as-threads rehearsal build)
 template <typename F>
 int guarded(F&& f) {
   try {

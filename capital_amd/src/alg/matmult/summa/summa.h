@@ -220,7 +220,7 @@ public:
     bool on;
     int base;
     explicit pipe(bool enable) : h(capital::handle()), on(enable) {
-      static int next = 0;
+      static CAPITAL_RANK_LOCAL int next = 0;
       base = next;
       next = (next + 256) % 1024;
     }
@@ -531,7 +531,7 @@ public:
   }
 
   static arena& scratch_arena() {
-    static arena a;
+    static CAPITAL_RANK_LOCAL arena a;
     return a;
   }
   template <typename MatrixType>

@@ -35,6 +35,15 @@
 #endif
 #endif
 
+// One rank per PROCESS is the product's model (one process per GPU).  -DCAPITAL_THREAD_RANKS makes the layer's three pieces of per-rank state
+// thread-local instead (this context, summa's scratch arena and event-slot counter), so that a rehearsal can run several ranks as threads of
+// one process -- tests/thread_ranks: the 2 x 2 x 2 grid's eight ranks on ONE GPU inside the pool's limit of six GPU processes.
+#ifdef CAPITAL_THREAD_RANKS
+#define CAPITAL_RANK_LOCAL thread_local
+#else
+#define CAPITAL_RANK_LOCAL
+#endif
+
 namespace capital {
 
 struct context {
@@ -45,7 +54,7 @@ struct context {
 };
 
 inline context& ctx() {
-  static context c;
+  static CAPITAL_RANK_LOCAL context c;
   return c;
 }
 

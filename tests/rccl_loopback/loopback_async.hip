@@ -59,9 +59,11 @@ struct Msg { uint32_t seq; size_t off, end; };
 struct Ring {                  // one direction of one channel, as THIS side sees it
   uint32_t gen = 0, seq = 0;
   size_t capacity = 0, head = 0;
-  char* base = nullptr;        // sender: its own allocation; receiver: the mapping
+  char* base = nullptr;        // sender: its own allocation; receiver: the mapping (or, for a peer in this very process, the sender's pointer)
+  bool base_local = false;     // receiver: `base` is a same-process pointer, nothing to close
   std::deque<Msg> live;
   std::vector<char*> retired;  // earlier generations: released at detach (messages may still be in flight in them)
+  std::vector<char*> by_gen;   // sender: ring base of every generation (a receiver thread of the same process asks for it by generation)
 };
 
 double timeout_s() {
@@ -143,6 +145,9 @@ struct AComm {
   char* map_dev = nullptr;      // its device alias (hipHostGetDevicePointer)
   bool registered = false;
   std::vector<Ring> tx, rx;     // per peer
+  std::vector<hipStream_t> streams;   // every stream this rank has used with the communicator (detach drains THESE, never the device)
+  std::vector<void*> old_scr;
+  void saw(hipStream_t s) { for (hipStream_t t : streams) if (t == s) return; streams.push_back(s); }
   void* scr = nullptr;
   size_t scr_bytes = 0;
   std::mutex mu;
@@ -156,6 +161,13 @@ namespace {
 struct Registry {
   std::mutex mu;
   std::vector<AComm*> comms;
+  // ranks of one communicator that live in THIS process (the ranks-as-threads rehearsal): the same device memory must not be IPC-opened
+  // by the process that exported it, so a receiver takes the sender's pointer instead
+  AComm* local_peer(const std::string& path, int rank) {
+    std::lock_guard<std::mutex> g(mu);
+    for (AComm* c : comms) if (c->path == path && c->rank == rank) return c;
+    return nullptr;
+  }
   bool started = false;
   void watch() {
     uint64_t last = ~0ull;
@@ -164,7 +176,7 @@ struct Registry {
       std::this_thread::sleep_for(std::chrono::milliseconds(500));
       uint64_t sum = 0;
       bool outstanding = false;
-      char what[512] = {0};
+      std::string what;
       {
         std::lock_guard<std::mutex> g(mu);
         for (AComm* c : comms) {
@@ -172,12 +184,13 @@ struct Registry {
           for (int p = 0; p < c->size; ++p) {
             if (p == c->rank) continue;
             const uint32_t posted = __atomic_load_n(&c->ch(p, c->rank)->posted, __ATOMIC_RELAXED), mine = __atomic_load_n(&c->ch(c->rank, p)->posted, __ATOMIC_RELAXED);
-            const uint32_t consumed = __atomic_load_n(&c->ch(c->rank, p)->consumed, __ATOMIC_RELAXED);
-            sum += (uint64_t)posted + mine + consumed;
-            if (c->rx[p].seq > posted || c->tx[p].seq > mine) {
-              if (!outstanding)
-                snprintf(what, sizeof(what), "%s rank %d <-> %d: receives issued %u, peer posted %u; sends issued %u, posted %u, peer consumed %u", c->path.c_str(),
-                         c->rank, p, c->rx[p].seq, posted, c->tx[p].seq, mine, consumed);
+            const uint32_t consumed = __atomic_load_n(&c->ch(c->rank, p)->consumed, __ATOMIC_RELAXED), eaten = __atomic_load_n(&c->ch(p, c->rank)->consumed, __ATOMIC_RELAXED);
+            sum += (uint64_t)posted + mine + consumed + eaten;
+            if (c->rx[p].seq > eaten || c->tx[p].seq > mine) {        // every channel with work of THIS rank still queued on the device
+              char line[384];
+              snprintf(line, sizeof(line), "\n    %s rank %d <-> %d: receives issued %u, peer posted %u, copied out %u; sends issued %u, posted %u, peer consumed %u",
+                       c->path.c_str(), c->rank, p, c->rx[p].seq, posted, eaten, c->tx[p].seq, mine, consumed);
+              if (what.size() < 6000) what += line;
               outstanding = true;
             }
           }
@@ -186,7 +199,7 @@ struct Registry {
       const auto now = std::chrono::steady_clock::now();
       if (!outstanding || sum != last) { last = sum; since = now; continue; }
       if (std::chrono::duration<double>(now - since).count() > timeout_s()) {
-        fprintf(stderr, "rccl_loopback (async): no device-side progress for %.0f s -- %s\n", timeout_s(), what);
+        fprintf(stderr, "rccl_loopback (async): no device-side progress for %.0f s; channels with queued work:%s\n", timeout_s(), what.c_str());
         fflush(stderr);
         _exit(86);
       }
@@ -272,18 +285,26 @@ void detach(AComm* c) {
     std::lock_guard<std::mutex> g(R.mu);
     for (size_t i = 0; i < R.comms.size(); ++i) if (R.comms[i] == c) { R.comms.erase(R.comms.begin() + i); break; }
   }
-  (void)hipDeviceSynchronize();                                      // (ncclCommDestroy is a synchronising call in RCCL too)
+  // (ncclCommDestroy is a synchronising call in RCCL too.)  The streams this rank used with the communicator are drained -- NOT the device: with
+  // several ranks as threads of one process (tests/thread_ranks) a device-wide wait would also wait for a sibling rank's stream, which may sit in a
+  // device-side wait for a message this rank has not enqueued yet.  For the same reason nothing is hipFree'd there (hipFree drains the device):
+  // CAPI_LOOPBACK_NO_FREE leaves the rings to the end of the process.
+  for (hipStream_t s_ : c->streams) (void)hipStreamSynchronize(s_);
+  static const bool no_free = getenv("CAPI_LOOPBACK_NO_FREE") != nullptr;
   const bool met = host_barrier(c);                                  // every rank's transfers have completed
   for (Ring& r : c->rx) {
-    if (r.base) (void)hipIpcCloseMemHandle(r.base);
+    if (r.base && !r.base_local) (void)hipIpcCloseMemHandle(r.base);
     for (char* p : r.retired) (void)hipIpcCloseMemHandle(p);
   }
   if (met) (void)host_barrier(c);                                    // every mapping is closed before its owner frees it
-  for (Ring& r : c->tx) {
-    if (r.base) (void)hipFree(r.base);
-    for (char* p : r.retired) (void)hipFree(p);
+  if (!no_free) {
+    for (Ring& r : c->tx) {
+      if (r.base) (void)hipFree(r.base);
+      for (char* p : r.retired) (void)hipFree(p);
+    }
+    if (c->scr) (void)hipFree(c->scr);
+    for (void* p : c->old_scr) (void)hipFree(p);
   }
-  if (c->scr) (void)hipFree(c->scr);
   if (c->registered) (void)hipHostUnregister(c->map);
   if (c->map) munmap(c->map, c->map_bytes);
   delete c;
@@ -291,8 +312,8 @@ void detach(AComm* c) {
 
 void* scratch(AComm* c, size_t bytes) {
   if (bytes > c->scr_bytes) {
-    // the old block may still be read by work in flight: it is only released once the device has drained (rare: sizes repeat)
-    if (c->scr) { (void)hipDeviceSynchronize(); (void)hipFree(c->scr); c->scr = nullptr; c->scr_bytes = 0; }
+    // the old block may still be read by work in flight: it is released with the communicator (rare: sizes repeat)
+    if (c->scr) { c->old_scr.push_back(c->scr); c->scr = nullptr; c->scr_bytes = 0; }
     size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
     if (hipMalloc(&c->scr, want) != hipSuccess) return nullptr;
     c->scr_bytes = want;
@@ -307,6 +328,7 @@ bool local_copy(void* dst, const void* src, size_t bytes, hipStream_t s, bool ac
 
 bool send(AComm* c, int peer, const void* buf, size_t bytes, hipStream_t s) {
   std::lock_guard<std::mutex> g(c->mu);
+  c->saw(s);
   Ring& r = c->tx[peer];
   Channel* ch = c->ch(c->rank, peer);
   uint32_t wait_seq = 0;
@@ -316,6 +338,8 @@ bool send(AComm* c, int peer, const void* buf, size_t bytes, hipStream_t s) {
     if (r.base) r.retired.push_back(r.base);
     r.base = nullptr;
     LB_HIP(hipMalloc((void**)&r.base, r.capacity));
+    r.by_gen.resize(r.gen + 1, nullptr);
+    r.by_gen[r.gen] = r.base;
     if (r.gen >= (uint32_t)MAX_GEN) { fprintf(stderr, "rccl_loopback (async): ring generations exhausted\n"); return false; }
     LB_HIP(hipIpcGetMemHandle(&ch->handle[r.gen], r.base));
     ch->capacity = r.capacity;
@@ -329,6 +353,7 @@ bool send(AComm* c, int peer, const void* buf, size_t bytes, hipStream_t s) {
 
 bool recv(AComm* c, int peer, void* buf, size_t bytes, hipStream_t s, bool accumulate) {
   std::unique_lock<std::mutex> g(c->mu);
+  c->saw(s);
   Ring& r = c->rx[peer];
   Channel* ch = c->ch(peer, c->rank);
   uint32_t wait_seq = 0;
@@ -343,11 +368,19 @@ bool recv(AComm* c, int peer, void* buf, size_t bytes, hipStream_t s, bool accum
       if (std::chrono::steady_clock::now() > t_end) { fprintf(stderr, "rccl_loopback (async): rank %d of %s: peer %d never published ring generation %u\n", c->rank, c->path.c_str(), peer, gen); return false; }
       std::this_thread::sleep_for(std::chrono::microseconds(20));
     }
+    char* local_base = nullptr;
+    if (AComm* pc = registry().local_peer(c->path, peer)) {          // the sender is a thread of this process
+      std::lock_guard<std::mutex> gp(pc->mu);
+      const Ring& t = pc->tx[c->rank];
+      if (gen < t.by_gen.size()) local_base = t.by_gen[gen];
+      if (!local_base) { fprintf(stderr, "rccl_loopback (async): same-process peer %d has no ring generation %u\n", peer, gen); return false; }
+    }
     g.lock();
-    if (r.base) r.retired.push_back(r.base);
+    if (r.base && !r.base_local) r.retired.push_back(r.base);
     r.base = nullptr;
     if (gen >= (uint32_t)MAX_GEN) return false;
-    LB_HIP(hipIpcOpenMemHandle((void**)&r.base, ch->handle[gen], hipIpcMemLazyEnablePeerAccess));
+    if (local_base) { r.base = local_base; r.base_local = true; }
+    else { LB_HIP(hipIpcOpenMemHandle((void**)&r.base, ch->handle[gen], hipIpcMemLazyEnablePeerAccess)); r.base_local = false; }
   }
   LB_HIP(hipStreamWaitValue32(s, c->dev(&ch->posted), seq, hipStreamWaitValueGte, 0xffffffffu));
   if (delay_us() > 0) { hipLaunchKernelGGL(lb_delay_kernel, dim3(1), dim3(1), 0, s, (long long)delay_us() * 100); LB_HIP(hipGetLastError()); }

@@ -225,3 +225,72 @@ def test_async_transport_catches_a_missing_consumer_wait(oracle):
                 except AssertionError:
                     caught = True
             assert caught, "the asynchronous transport did not expose the missing wait:\n" + "\n".join(o[-1500:] for o in outs)
+
+
+THREAD_DRIVER = os.path.join(HERE, "thread_ranks", "libcapital_driver_threads.so")
+
+
+def _launch_thread_ranks(nproc, threads, cfg, mode, timeout=int(os.environ.get("CAPITAL_TEST_RANK_TIMEOUT_S", "900"))):
+    procs = []
+    for p in range(nproc):
+        env = dict(os.environ, PROC_INDEX=str(p), NPROC=str(nproc), THREADS_PER_PROC=str(threads), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   CAPITAL_MIN_CHUNK_COLS="64", CAPI_RCCL_LIB=LOOPBACK, CAPI_LOOPBACK_MODE=mode, CAPITAL_DRIVER_LIB=THREAD_DRIVER)
+        # Every HIP stream of every rank needs a hardware queue of its OWN: the HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES
+        # (default 4) queues, and two ranks whose streams share a queue deadlock in the asynchronous mode -- rank A's device-side wait for rank B's
+        # message blocks the very queue B's copy kernel sits in (measured: 2 processes x 4 threads stall in the first case; host-staged mode passes)
+        env.setdefault("GPU_MAX_HW_QUEUES", "16")
+        # ... and nobody may drain the DEVICE: hipFree does (it waits for every stream of the process), so a rank that frees a block while its sibling's
+        # stream sits in a device-side wait for a message the freeing rank has not enqueued yet never returns (measured: the second case stalls in
+        # the validator's frees).  The product defers its frees to capi_destroy, the transport leaves its rings to the end of the process.
+        env.setdefault("CAPI_DEFER_FREE", "1")
+        env.setdefault("CAPI_LOOPBACK_NO_FREE", "1")
+        env.setdefault("CAPI_LOOPBACK_TIMEOUT_S", "90")
+        logdir = os.environ.get("CAPITAL_TEST_RANK_LOG_DIR")
+        out = open(os.path.join(logdir, f"threads_proc{p}_of{nproc}_{mode}.log"), "w") if logdir else subprocess.PIPE
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.join(HERE, "_gpu_thread_ranks_main.py"), json.dumps(cfg)], env=env,
+                                      stdout=out, stderr=subprocess.STDOUT, text=True))
+    outs, timed_out = [], False
+    try:
+        for p in procs:
+            o, _ = p.communicate(timeout=timeout)
+            outs.append(o or "")
+    except subprocess.TimeoutExpired:
+        timed_out = True
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    if timed_out:
+        outs = [p.communicate()[0] or "" for p in procs]
+    assert not timed_out and all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
+
+
+@pytest.mark.parametrize("mode", ["host", "async"])
+def test_eight_ranks_as_threads_2x2x2_grid_and_cacqr_3d(oracle, mode):
+    """BASELINE config 4's own grid, 2 x 2 x 2, on a REAL GPU: eight ranks as threads of four processes (tests/thread_ranks: the host layer with its
+    per-rank state thread-local; the pool allows six GPU processes, eight one-rank processes are out of reach), all on GPU 0 over the loopback
+    transport in both of its modes.  What had only run on gloo before: the cubic grid's SUMMA with depth all-reduces, the multi-path transfer
+    sets at P = 8 (every message cut into eight units, six of them relayed), rank layout 1, TRSM mode on the cube, and the 3-D CholeskyQR2
+    (cacqr.hpp:31-170: Gram by broadcast + product + reduce + broadcast, the distributed cholinv on the c x c x c cube, SUMMA right-TRMM) with
+    and without the chunk pipeline.  Factors against the 1-rank oracle, as in the one-rank-per-process cases."""
+    subprocess.check_call(["make", "-C", os.path.dirname(LOOPBACK), "-s"])
+    subprocess.check_call(["make", "-C", os.path.dirname(THREAD_DRIVER), "-s"])
+    world, c, n = 8, 2, 4096
+    cases = [
+        {"tag": "ch_p0", "kind": "cholinv", "n": n, "c": c, "bc": -3, "ci": 1, "serialize": True, "policy": 0},
+        {"tag": "ch_p3", "kind": "cholinv", "n": n + 40, "c": c, "bc": -2, "ci": 0, "serialize": False, "policy": 3},
+        {"tag": "ch_chunks", "kind": "cholinv", "n": n, "c": c, "bc": -3, "ci": 1, "serialize": True, "policy": 0, "chunks": 3},
+        {"tag": "ch_mp", "kind": "cholinv", "n": n, "c": c, "bc": -3, "ci": 1, "serialize": True, "policy": 0,
+         "env": {"CAPITAL_MULTIPATH": "1", "CAPITAL_MULTIPATH_MIN": "4096"}},
+        {"tag": "ch_mp_chunks", "kind": "cholinv", "n": n + 40, "c": c, "bc": -3, "ci": 1, "serialize": False, "policy": 2, "chunks": 4,
+         "env": {"CAPITAL_MULTIPATH": "1", "CAPITAL_MULTIPATH_MIN": "4096"}},
+        {"tag": "ch_trsm", "kind": "cholinv", "n": n + 40, "c": c, "bc": -3, "ci": 0, "serialize": True, "policy": 0, "trsm": True},
+        {"tag": "ch_l1", "kind": "cholinv", "n": n, "c": c, "bc": -3, "ci": 1, "serialize": False, "policy": 0, "layout": 1},
+        {"tag": "qr", "kind": "cacqr", "m": (1 << 13) * world, "n": 256, "serialize": True},
+        {"tag": "qr3d", "kind": "cacqr", "m": 1 << 14, "n": 512, "c": 2, "ci": 1, "bc": -1, "serialize": False},
+        {"tag": "qr3d_chunks", "kind": "cacqr", "m": 1 << 14, "n": 512, "c": 2, "ci": 0, "bc": -1, "serialize": False, "chunks": 3,
+         "env": {"CAPITAL_MULTIPATH_MIN": "4096"}},
+    ]
+    with tempfile.TemporaryDirectory() as d:
+        _launch_thread_ranks(4, 2, {"dir": d, "cases": cases}, mode)
+        _check_cases(oracle, d, cases, world, c)

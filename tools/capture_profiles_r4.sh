@@ -24,7 +24,7 @@ timeout -k 10 900 python bench.py --steps 3 > $O/bench.json 2> $O/bench.err; leg
 timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/tr -o b -- python bench.py --steps 3 --no-cpu > $O/bench_under_rocprof.json 2> $O/rp.err; rc=$?
 if [ $rc -eq 0 ]; then
   F=$(find $O/tr -name "b_kernel_trace.csv" | head -1)
-  { python tools/timed_region_stats.py $F 3 1 "$TILE"; python tools/timed_region_stats.py $F 3 1 "$PAIR"; python tools/timed_region_stats.py $F 3 1 "<true, true>"; } > $O/timed_region.txt; rc=$?
+  { python tools/timed_region_stats.py $F 3 1 "$TILE"; python tools/timed_region_stats.py $F 3 1 "$PAIR"; python tools/timed_region_stats.py $F 3 1 "$TILE|$PAIR"; } > $O/timed_region.txt; rc=$?
   cp $(find $O/tr -name "b_kernel_stats.csv" | head -1) $O/kernel_stats.csv
   python tools/gap_analysis.py $F 4 > $O/gaps_n65536.txt 2>&1 || true        # W + K = 4 factor() calls of the headline
 fi

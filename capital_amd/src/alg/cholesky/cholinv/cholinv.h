@@ -367,12 +367,17 @@ private:
   // lookahead (single GPU): slot + depth; the bulk streams are stream indices LA_STREAM0 + depth
   static constexpr int EV_BC_POTRF = 1008, EV_BC_SCATTER = 1009;      // NoReplicationOverlap: scatter of R beside trtri
   static constexpr int EV_LA_LEAD = 1010, EV_LA_REST = 1014, LA_STREAM0 = 2, LA_MAX_DEPTH = 2;
-  // smallest trailing block whose update is split (CAPITAL_LOOKAHEAD_MIN, default 2048; CAPITAL_NO_LOOKAHEAD turns it off);
-  // read per call so that tests can exercise the path at small orders
+  // smallest trailing block whose update is split; read per call so that tests can exercise the path at small orders.
+  // OFF by default since round 4 (CAPITAL_LOOKAHEAD=1: from order 2048; CAPITAL_LOOKAHEAD_MIN=n: from order n; CAPITAL_NO_LOOKAHEAD: off whatever else is set).
+  // Measured on one box with launches in resident rounds, alternating: n = 65536 1705.5 / 1706.0 ms with the lookahead against 1699.5 / 1700.4 without,
+  // n = 32768 237.9 / 237.9 against 236.7 / 236.6 (profiles/r4_lookahead_ab.txt).  Why it cannot pay: the chain's kernels need what a resident tile
+  // workgroup holds -- the diagonal-block kernel 132 KB of LDS, i.e. a CU with NO tile workgroup on it -- so beside a bulk launch the chain advances
+  // only when a resident round drains (one kernel per 2-4 ms), while the bulk's rounds run at 0.86-0.88 of peak beside it instead of 0.91-0.92 alone.
   static int64_t lookahead_min() {
     if (getenv("CAPITAL_NO_LOOKAHEAD")) return -1;
     const char* e = getenv("CAPITAL_LOOKAHEAD_MIN");
-    return e ? (int64_t)atoll(e) : (int64_t)2048;
+    if (e) return (int64_t)atoll(e);
+    return getenv("CAPITAL_LOOKAHEAD") ? (int64_t)2048 : -1;
   }
 
   // how many trailing updates may run beside the recursion at once (CAPITAL_LA_DEPTH, default and maximum LA_MAX_DEPTH = 2 bulk streams)

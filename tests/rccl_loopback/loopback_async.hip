@@ -21,6 +21,7 @@
 // the consumption of messages at least three back: inside one ncclGroup at most three messages per (communicator, peer, direction).
 // A watchdog thread ends the process with a diagnosis when device-side waits stop making progress (CAPI_LOOPBACK_TIMEOUT_S).
 #include "loopback_async.h"
+#include "ring_place.h"
 
 #include <atomic>
 #include <chrono>
@@ -55,17 +56,6 @@ struct alignas(256) Header {
 };
 constexpr uint32_t MAGIC = 0x4c424153u;
 
-struct Msg { uint32_t seq; size_t off, end; };
-struct Ring {                  // one direction of one channel, as THIS side sees it
-  uint32_t gen = 0, seq = 0;
-  size_t capacity = 0, head = 0;
-  char* base = nullptr;        // sender: its own allocation; receiver: the mapping (or, for a peer in this very process, the sender's pointer)
-  bool base_local = false;     // receiver: `base` is a same-process pointer, nothing to close
-  std::deque<Msg> live;
-  std::vector<char*> retired;  // earlier generations: released at detach (messages may still be in flight in them)
-  std::vector<char*> by_gen;   // sender: ring base of every generation (a receiver thread of the same process asks for it by generation)
-};
-
 double timeout_s() {
   const char* e = getenv("CAPI_LOOPBACK_TIMEOUT_S");
   return e ? atof(e) : 120.0;
@@ -77,34 +67,6 @@ int copy_wgs() {
 long delay_us() {
   static const long v = [] { const char* e = getenv("CAPI_LOOPBACK_DELAY_US"); long d = e ? atol(e) : 0; return d < 0 ? 0 : (d > 1000000 ? 1000000 : d); }();
   return v;
-}
-
-// The placement rule both sides run.  Returns the offset of the message and, through wait_seq, the newest earlier message whose region it
-// overlaps (0: none) -- the sender must not write before that one has been consumed.  grew: a new generation starts with this message.
-size_t ring_place(Ring& r, size_t bytes, uint32_t& wait_seq, bool& grew) {
-  const size_t need = (bytes + 255) & ~(size_t)255;
-  grew = false;
-  wait_seq = 0;
-  if (4 * need > r.capacity || r.gen == 0) {
-    size_t cap = (size_t)1 << 20;
-    while (cap < 4 * need) cap <<= 1;
-    if (cap < r.capacity) cap = r.capacity;
-    r.capacity = cap;
-    r.head = 0;
-    r.live.clear();
-    ++r.gen;
-    grew = true;
-  }
-  if (r.head + need > r.capacity) r.head = 0;
-  const size_t off = r.head, end = off + need;
-  while (!r.live.empty() && r.live.front().off < end && r.live.front().end > off) {      // the oldest messages are the ones in the way
-    wait_seq = r.live.front().seq;
-    r.live.pop_front();
-  }
-  ++r.seq;
-  r.live.push_back({r.seq, off, end});
-  r.head = end;
-  return off;
 }
 
 __global__ void lb_copy_kernel(char* __restrict__ dst, const char* __restrict__ src, size_t bytes, int accumulate) {

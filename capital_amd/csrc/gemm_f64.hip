@@ -1579,6 +1579,7 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
       p.a_vec = (((uintptr_t)p.A & 15) == 0) && ((p.lda & 1) == 0);
       p.splitk = 1;
       static const bool rows16 = getenv("CAPI_TS_ROWS16") != nullptr;     // the 16-row-tile variant (A/B)
+      CAPI_REQUIRE(h, !(rows16 && (p.a_tiled || p.c_tiled)), "panel32 images need the 32-row T-stationary kernel");
       const int rows = rows16 ? 16 : 32;
       const int ntile = (int)cdiv(p.M, rows);
       const int grid = ntile < h->num_cu ? ntile : h->num_cu;
@@ -1647,6 +1648,10 @@ int launch_gemm(capi_handle_t h, bool ak, bool bkc, GemmArgs& p, bool ws_for_sla
       return CAPI_OK;
     }
   }
+  // (panel32 images are understood by the two full-width tall-skinny kernels above and by nothing below: the entry points check the switches that
+  //  could route such an operand here -- CAPI_NO_TS, CAPI_TS_ROWS16 -- per call, the dispatch above reads them once per process, so a process that
+  //  changes them between calls must get a refusal, not a tile kernel that reads an image as column-major with ld 32)
+  CAPI_REQUIRE(h, !p.a_tiled && !p.c_tiled, "panel32 operand reached a kernel that does not read it");
   // Choose tile size and split-K from a small cost model in CU-cycles.  One k-panel (16 deep) of a 128-tile keeps all
   // four MFMA pipes of a CU busy for 64 MFMAs x 64 cycles = 4096 cycles, of a 64-tile for 1024; co-resident workgroups
   // share the pipes, so a CU works through the tiles dealt to it at that rate whatever their number.  The makespan is

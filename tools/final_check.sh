@@ -1,5 +1,8 @@
-# HEAD check on a GPU box: the driver's own sequence (GPU tests with -x, smoke, default bench)
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && O=gpurun_out/final && rm -rf $O && mkdir -p $O
-timeout -k 10 1100 python -m pytest tests -x -q -m gpu > $O/tests.log 2>&1; tail -4 $O/tests.log
-timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
-timeout -k 10 900 python bench.py > $O/bench.json 2> $O/bench.err; cut -c1-300 $O/bench.json; tail -2 $O/bench.err
+#!/bin/bash
+# what the driver runs at the end of a round, in one gpurun call: the GPU suite, smoke(), the default bench line
+export TMPDIR=/tmp
+O=gpurun_out/final; rm -rf $O; mkdir -p $O
+timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/legs.txt; tail -3 $O/pytest.log
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $O/legs.txt; tail -3 $O/smoke.log
+timeout -k 10 600 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" | tee -a $O/legs.txt
+cut -c1-1500 $O/bench.json

@@ -17,6 +17,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+T0 = time.time()
+
+
 def main():
     cfg = json.loads(sys.argv[1])
     proc, nproc, T = int(os.environ["PROC_INDEX"]), int(os.environ["NPROC"]), int(os.environ["THREADS_PER_PROC"])
@@ -56,7 +59,7 @@ def main():
                     for k in ("CAPITAL_MULTIPATH", "CAPITAL_MULTIPATH_MIN"):
                         os.environ.pop(k, None)
                     os.environ.update(case.get("env", {}))
-                    print(f"process {proc}: case {tag} starts", flush=True)
+                    print(f"process {proc}: case {tag} starts at +{time.time() - T0:.1f} s", flush=True)
                 bar.wait()
                 if case["kind"] == "cholinv":
                     p = driver.Cholinv(case["n"], c=case["c"], complete_inv=case["ci"], split=1, bc_mult=case["bc"], layout=case.get("layout", 0),
@@ -79,7 +82,7 @@ def main():
                     q.close()
             bar.wait()
             driver._ck(D.capital_drv_finalize(), "finalize")
-            print(f"rank {rank} ok", flush=True)
+            print(f"rank {rank} ok at +{time.time() - T0:.1f} s", flush=True)
         except BaseException as e:          # a rank that fails must take the process down: its peers would wait in a collective
             failures.append((rank, repr(e)))
             traceback.print_exc()

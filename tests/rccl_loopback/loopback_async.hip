@@ -48,6 +48,9 @@ struct alignas(256) Channel {
   uint32_t gen;               // host-written by the sender (release): generation of the ring it has published
   uint32_t pad_;
   uint64_t capacity;          // bytes of that generation
+  // device-written by the receiver's check kernel: the first message whose bytes, as the receiver finds them in the ring, do not give the sender's checksum
+  uint32_t bad_seq, bad_pad_;
+  uint64_t bad_record[8];     // what it saw (lb_check_kernel)
   hipIpcMemHandle_t handle[MAX_GEN];   // one per generation (a ring at least doubles when it grows: 1 MiB .. 2^(20 + MAX_GEN) bytes), so a receiver
                                        // that lags its sender by several growths still maps the generation its message sits in
 };
@@ -64,13 +67,33 @@ int copy_wgs() {
   static const int v = [] { const char* e = getenv("CAPI_LOOPBACK_COPY_WGS"); int w = e ? atoi(e) : 16; return w < 1 ? 1 : (w > 1024 ? 1024 : w); }();
   return v;
 }
+bool verify() {
+  static const bool v = [] { const char* e = getenv("CAPI_LOOPBACK_VERIFY"); return !e || atoi(e) != 0; }();      // on unless CAPI_LOOPBACK_VERIFY=0
+  return v;
+}
 long delay_us() {
   static const long v = [] { const char* e = getenv("CAPI_LOOPBACK_DELAY_US"); long d = e ? atol(e) : 0; return d < 0 ? 0 : (d > 1000000 ? 1000000 : d); }();
   return v;
 }
 
-__global__ void lb_copy_kernel(char* __restrict__ dst, const char* __restrict__ src, size_t bytes, int accumulate) {
+// `coherent`: the source is a ring that another rank's kernel has just written -- read it past the caches (system-scope loads).  A peer in another PROCESS is read
+// through an IPC mapping; a peer that is a THREAD of this process (tests/thread_ranks) through the very pointer its kernel wrote, whose lines this XCD's L2 may still hold
+// from the slot's previous lap: nothing the HIP runtime knows of orders the two kernels (the ordering is the stream wait-value), so no cache maintenance is implied.
+__global__ void lb_copy_kernel(char* __restrict__ dst, const char* __restrict__ src, size_t bytes, int accumulate, int coherent) {
   const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, nthr = (size_t)gridDim.x * blockDim.x;
+  // coherent > 0 (receive side): drop whatever this XCD's caches hold of the ring BEFORE reading it (system-scope acquire: buffer_inv sc0 sc1);
+  // coherent < 0 (send side): push the ring's new contents out of this XCD's L2 when done (system-scope release: buffer_wbl2), see the end of the kernel
+  if (coherent > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  if (coherent > 0 && ((((uintptr_t)dst) | ((uintptr_t)src) | bytes) & 7) == 0) {
+    unsigned long long* d = (unsigned long long*)dst;
+    const unsigned long long* s = (const unsigned long long*)src;
+    for (size_t i = tid; i < bytes / 8; i += nthr) {
+      const unsigned long long v = __hip_atomic_load(s + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (accumulate) ((double*)d)[i] = ((double*)d)[i] + __longlong_as_double((long long)v); else d[i] = v;
+    }
+    return;
+  }
+  struct Release { int on; __device__ ~Release() { if (on) __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); } } release_at_end{coherent < 0};
   const bool al16 = ((((uintptr_t)dst) | ((uintptr_t)src)) & 15) == 0;
   if (accumulate) {                                   // doubles (the reductions' only type here)
     double* d = (double*)dst;
@@ -86,8 +109,57 @@ __global__ void lb_copy_kernel(char* __restrict__ dst, const char* __restrict__ 
     for (size_t i = tid; i < n16; i += nthr) d[i] = s[i];
     done = n16 * 16;
   }
-  for (size_t i = done + tid; i < bytes; i += nthr) dst[i] = src[i];
+  for (size_t i = done + tid; i < bytes; i += nthr) dst[i] = coherent > 0 ? __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : src[i];
 }
+// Every message carries a checksum: the sender sums (xor of the 8-byte words, the odd bytes folded in) what it has put into the ring and leaves the sum in the message's
+// trailer; the receiver sums what IT finds in the ring, after its copy and before it reports the message consumed, and records a mismatch in the channel's control block
+// (the watchdog reports it and ends the process).  A message overwritten too early, read too early or read stale is then an error of the TRANSPORT with a name --
+// communicator, pair, sequence number -- instead of a wrong factor somewhere downstream.  One workgroup; these are test messages.
+__device__ unsigned long long lb_sum_of(const char* p, size_t bytes, bool coherent) {
+  __shared__ unsigned long long part[256];
+  unsigned long long x = 0;
+  const unsigned long long* w = (const unsigned long long*)p;           // (ring slots are 256-byte aligned)
+  for (size_t i = threadIdx.x; i < bytes / 8; i += blockDim.x) x ^= coherent ? __hip_atomic_load(w + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : w[i];
+  for (size_t i = (bytes & ~(size_t)7) + threadIdx.x; i < bytes; i += blockDim.x) x ^= (unsigned long long)(unsigned char)p[i] << (8 * (i & 7));
+  part[threadIdx.x] = x;
+  __syncthreads();
+  for (int s_ = 128; s_ > 0; s_ >>= 1) { if ((int)threadIdx.x < s_) part[threadIdx.x] ^= part[threadIdx.x + s_]; __syncthreads(); }
+  return part[0];
+}
+// trailer of a message: [0] checksum, [1] length, [2] sequence number on its channel, [3] identity of the channel (hash of the communicator's name, source, destination)
+__global__ __launch_bounds__(256) void lb_sum_kernel(const char* slot, size_t bytes, unsigned long long* trailer, unsigned long long seq, unsigned long long ident) {
+  const unsigned long long x = lb_sum_of(slot, bytes, false);
+  if (threadIdx.x == 0) { trailer[0] = x; trailer[1] = (unsigned long long)bytes; trailer[2] = seq; trailer[3] = ident; __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); }
+}
+// On a mismatch the receiver looks a SECOND time, two milliseconds later, and records both views: bytes that have become right were read too early (an ordering
+// failure); a trailer that names a later message of this channel was overwritten too early (flow control); one that names another channel, or nothing, is another
+// block of memory (the mapping).  record[0..7] = trailer as first seen (4 words), the sum first found, then sum / trailer[0] / trailer[2] of the second look.
+__global__ __launch_bounds__(256) void lb_check_kernel(const char* slot, size_t bytes, const unsigned long long* trailer, uint32_t seq, unsigned long long ident, uint32_t* bad_seq,
+                                                       unsigned long long* record) {
+  __shared__ int mismatch;
+  __shared__ unsigned long long seen[4];
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  const unsigned long long x = lb_sum_of(slot, bytes, true);
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < 4; ++i) seen[i] = __hip_atomic_load(trailer + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    mismatch = (seen[0] != x || seen[1] != (unsigned long long)bytes || seen[2] != seq || seen[3] != ident) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!mismatch) return;
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < 200000) __builtin_amdgcn_s_sleep(64);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  __syncthreads();
+  const unsigned long long x2 = lb_sum_of(slot, bytes, true);
+  if (threadIdx.x == 0 && atomicCAS(bad_seq, 0u, seq) == 0u) {
+    for (int i = 0; i < 4; ++i) record[i] = seen[i];
+    record[4] = x;
+    record[5] = x2;
+    record[6] = __hip_atomic_load(trailer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    record[7] = __hip_atomic_load(trailer + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // a bounded wait (the wall clock runs at 100 MHz): leaves on its own, whatever happens elsewhere
 __global__ void lb_delay_kernel(long long ticks) {
   const long long t0 = wall_clock64();
@@ -96,6 +168,11 @@ __global__ void lb_delay_kernel(long long ticks) {
 
 struct Registry;
 Registry& registry();
+uint64_t ident_of(const std::string& path, int src, int dst) {
+  uint64_t h = 1469598103934665603ull;
+  for (char ch : path) { h ^= (unsigned char)ch; h *= 1099511628211ull; }
+  return (h << 16) ^ ((uint64_t)(src & 0xff) << 8) ^ (uint64_t)(dst & 0xff) ^ 0x4c42000000000000ull;
+}
 
 }  // namespace
 
@@ -148,6 +225,23 @@ struct Registry {
             const uint32_t posted = __atomic_load_n(&c->ch(p, c->rank)->posted, __ATOMIC_RELAXED), mine = __atomic_load_n(&c->ch(c->rank, p)->posted, __ATOMIC_RELAXED);
             const uint32_t consumed = __atomic_load_n(&c->ch(c->rank, p)->consumed, __ATOMIC_RELAXED), eaten = __atomic_load_n(&c->ch(p, c->rank)->consumed, __ATOMIC_RELAXED);
             sum += (uint64_t)posted + mine + consumed + eaten;
+            const uint32_t bad = __atomic_load_n(&c->ch(p, c->rank)->bad_seq, __ATOMIC_RELAXED);
+            if (bad) {
+              const Channel* ch_ = c->ch(p, c->rank);
+              const uint64_t* w = ch_->bad_record;
+              fprintf(stderr, "rccl_loopback (async): DATA CHECK FAILED on %s: message %u from rank %d to rank %d (channel identity %016llx; receives issued %u, posted %u, copied out %u; the sender is %s)\n"
+                      "    the trailer in the ring read: checksum %016llx, length %llu, sequence %llu, identity %016llx; the receiver's sum over the slot: %016llx\n"
+                      "    two milliseconds later: sum %016llx, trailer checksum %016llx, sequence %llu  =>  %s\n", c->path.c_str(), bad, p, c->rank,
+                      (unsigned long long)ident_of(c->path, p, c->rank), c->rx[p].seq, posted, eaten, c->rx[p].base_local ? "a thread of this process" : "another process",
+                      (unsigned long long)w[0], (unsigned long long)w[1], (unsigned long long)w[2], (unsigned long long)w[3], (unsigned long long)w[4], (unsigned long long)w[5],
+                      (unsigned long long)w[6], (unsigned long long)w[7],
+                      (w[5] == w[6] && w[7] == bad) ? "the bytes ARRIVED LATER: the receiver read before the sender had written (ordering)"
+                      : (w[3] == ident_of(c->path, p, c->rank) && w[2] > bad) ? "a LATER message of this channel lies there: overwritten before it was consumed (flow control)"
+                      : (w[3] == ident_of(c->path, p, c->rank)) ? "this channel's trailer, other bytes"
+                      : "not a trailer of this channel: the receiver looks at other memory than the sender wrote (the mapping), or the slot was never written");
+              fflush(stderr);
+              _exit(87);
+            }
             if (c->rx[p].seq > eaten || c->tx[p].seq > mine) {        // every channel with work of THIS rank still queued on the device
               char line[384];
               snprintf(line, sizeof(line), "\n    %s rank %d <-> %d: receives issued %u, peer posted %u, copied out %u; sends issued %u, posted %u, peer consumed %u",
@@ -192,9 +286,20 @@ bool host_barrier(AComm* c) {
     if (e__ != hipSuccess) { fprintf(stderr, "rccl_loopback (async): %s:%d %s -> %s\n", __FILE__, __LINE__, #call, hipGetErrorString(e__)); return false; } \
   } while (0)
 
-bool launch_copy(void* dst, const void* src, size_t bytes, hipStream_t s, bool accumulate) {
+// Every ring ends in a LABEL the sender writes before it publishes the ring (which channel, which generation): a receiver that has opened the handle reads the label back
+// through its mapping, so a mapping that does not show the sender's memory is found when it is made, not by a wrong factor later.
+struct Label { uint64_t magic, ident, gen, capacity; };
+constexpr uint64_t LABEL_MAGIC = 0x4c424c4142454c21ull;
+constexpr size_t LABEL_BYTES = 4096;
+// diagnostics (profiles/r4_eight_thread_ranks_2x2x2.txt): CAPI_LOOPBACK_LABEL=0 keeps the ring's size (capacity + 4096) and skips the label; =-1 also drops the 4096 bytes
+int label_mode() { static const int v = [] { const char* e = getenv("CAPI_LOOPBACK_LABEL"); return e ? atoi(e) : 1; }(); return v; }
+
+// export and import of ring memory, one call at a time per process (ranks as threads of one process would otherwise run them concurrently)
+std::mutex& ipc_mu() { static std::mutex* m = new std::mutex(); return *m; }
+
+bool launch_copy(void* dst, const void* src, size_t bytes, hipStream_t s, bool accumulate, int coherent = 0) {
   if (bytes == 0) return true;
-  hipLaunchKernelGGL(lb_copy_kernel, dim3((unsigned)copy_wgs()), dim3(256), 0, s, (char*)dst, (const char*)src, bytes, accumulate ? 1 : 0);
+  hipLaunchKernelGGL(lb_copy_kernel, dim3((unsigned)copy_wgs()), dim3(256), 0, s, (char*)dst, (const char*)src, bytes, accumulate ? 1 : 0, coherent);
   LB_HIP(hipGetLastError());
   return true;
 }
@@ -299,16 +404,26 @@ bool send(AComm* c, int peer, const void* buf, size_t bytes, hipStream_t s) {
   if (grew) {
     if (r.base) r.retired.push_back(r.base);
     r.base = nullptr;
-    LB_HIP(hipMalloc((void**)&r.base, r.capacity));
+    if (r.gen >= (uint32_t)MAX_GEN) { fprintf(stderr, "rccl_loopback (async): ring generations exhausted\n"); return false; }
+    {
+      std::lock_guard<std::mutex> gi(ipc_mu());
+      LB_HIP(hipMalloc((void**)&r.base, r.capacity + (label_mode() >= 0 ? LABEL_BYTES : 0)));
+      const Label lab{LABEL_MAGIC, ident_of(c->path, c->rank, peer), r.gen, r.capacity};
+      if (label_mode() > 0) LB_HIP(hipMemcpy(r.base + r.capacity, &lab, sizeof(lab), hipMemcpyHostToDevice));          // (synchronous: in place before the handle exists)
+      LB_HIP(hipIpcGetMemHandle(&ch->handle[r.gen], r.base));
+    }
     r.by_gen.resize(r.gen + 1, nullptr);
     r.by_gen[r.gen] = r.base;
-    if (r.gen >= (uint32_t)MAX_GEN) { fprintf(stderr, "rccl_loopback (async): ring generations exhausted\n"); return false; }
-    LB_HIP(hipIpcGetMemHandle(&ch->handle[r.gen], r.base));
     ch->capacity = r.capacity;
     __atomic_store_n(&ch->gen, r.gen, __ATOMIC_RELEASE);
   }
   if (wait_seq) LB_HIP(hipStreamWaitValue32(s, c->dev(&ch->consumed), wait_seq, hipStreamWaitValueGte, 0xffffffffu));
-  if (!launch_copy(r.base + off, buf, bytes, s, false)) return false;
+  if (!launch_copy(r.base + off, buf, bytes, s, false, /*coherent: release at the end*/ -1)) return false;
+  if (verify()) {
+    hipLaunchKernelGGL(lb_sum_kernel, dim3(1), dim3(256), 0, s, r.base + off, bytes, (unsigned long long*)(r.base + r.live.back().end - 256), (unsigned long long)r.seq,
+                       (unsigned long long)ident_of(c->path, c->rank, peer));
+    LB_HIP(hipGetLastError());
+  }
   LB_HIP(hipStreamWriteValue32(s, c->dev(&ch->posted), r.seq, 0));
   return true;
 }
@@ -321,6 +436,7 @@ bool recv(AComm* c, int peer, void* buf, size_t bytes, hipStream_t s, bool accum
   uint32_t wait_seq = 0;
   bool grew = false;
   const size_t off = ring_place(r, bytes, wait_seq, grew);
+  const size_t trailer_off = r.live.back().end - 256;
   const uint32_t seq = r.seq, gen = r.gen;
   if (grew) {
     // the one place where a host meets its peer's HOST: the sender has to have published this generation of the ring
@@ -342,11 +458,36 @@ bool recv(AComm* c, int peer, void* buf, size_t bytes, hipStream_t s, bool accum
     r.base = nullptr;
     if (gen >= (uint32_t)MAX_GEN) return false;
     if (local_base) { r.base = local_base; r.base_local = true; }
-    else { LB_HIP(hipIpcOpenMemHandle((void**)&r.base, ch->handle[gen], hipIpcMemLazyEnablePeerAccess)); r.base_local = false; }
+    else {
+      std::lock_guard<std::mutex> gi(ipc_mu());
+      const Label want{LABEL_MAGIC, ident_of(c->path, peer, c->rank), gen, r.capacity};
+      for (int attempt = 1;; ++attempt) {
+        LB_HIP(hipIpcOpenMemHandle((void**)&r.base, ch->handle[gen], hipIpcMemLazyEnablePeerAccess));
+        if (label_mode() <= 0) break;
+        Label got{};
+        LB_HIP(hipMemcpy(&got, r.base + r.capacity, sizeof(got), hipMemcpyDeviceToHost));
+        if (got.magic == want.magic && got.ident == want.ident && got.gen == want.gen && got.capacity == want.capacity) break;
+        fprintf(stderr, "rccl_loopback (async): %s: rank %d opened ring generation %u of peer %d (%zu bytes) and finds the label {%016llx %016llx gen %llu capacity %llu} where the sender wrote "
+                "{%016llx %016llx gen %llu capacity %llu}: the mapping at %p does not show the sender's memory (attempt %d)\n", c->path.c_str(), c->rank, gen, peer, r.capacity,
+                (unsigned long long)got.magic, (unsigned long long)got.ident, (unsigned long long)got.gen, (unsigned long long)got.capacity, (unsigned long long)want.magic,
+                (unsigned long long)want.ident, (unsigned long long)want.gen, (unsigned long long)want.capacity, (void*)r.base, attempt);
+        fflush(stderr);
+        (void)hipIpcCloseMemHandle(r.base);
+        r.base = nullptr;
+        if (attempt == 5) return false;
+        std::this_thread::sleep_for(std::chrono::milliseconds(2));
+      }
+      r.base_local = false;
+    }
   }
   LB_HIP(hipStreamWaitValue32(s, c->dev(&ch->posted), seq, hipStreamWaitValueGte, 0xffffffffu));
   if (delay_us() > 0) { hipLaunchKernelGGL(lb_delay_kernel, dim3(1), dim3(1), 0, s, (long long)delay_us() * 100); LB_HIP(hipGetLastError()); }
-  if (!launch_copy(buf, r.base + off, bytes, s, accumulate)) return false;
+  if (!launch_copy(buf, r.base + off, bytes, s, accumulate, /*coherent: acquire + system-scope loads*/ 1)) return false;
+  if (verify()) {
+    hipLaunchKernelGGL(lb_check_kernel, dim3(1), dim3(256), 0, s, r.base + off, bytes, (const unsigned long long*)(r.base + trailer_off), seq,
+                       (unsigned long long)ident_of(c->path, peer, c->rank), c->dev(&ch->bad_seq), (unsigned long long*)c->dev(&ch->bad_record[0]));
+    LB_HIP(hipGetLastError());
+  }
   LB_HIP(hipStreamWriteValue32(s, c->dev(&ch->consumed), seq, 0));
   return true;
 }

@@ -3,6 +3,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <deque>
 #include <vector>
 
@@ -22,11 +23,13 @@ struct Ring {                  // one direction of one channel, as THIS side see
 // The placement rule both sides run.  Returns the offset of the message and, through wait_seq, the newest earlier message whose region it
 // overlaps (0: none) -- the sender must not write before that one has been consumed.  grew: a new generation starts with this message.
 inline size_t ring_place(Ring& r, size_t bytes, uint32_t& wait_seq, bool& grew) {
-  const size_t need = (bytes + 255) & ~(size_t)255;
+  const size_t need = ((bytes + 255) & ~(size_t)255) + 256;      // the message and a 256-byte trailer (its checksum, written by the sender: loopback_async.hip lb_sum_kernel)
   grew = false;
   wait_seq = 0;
   if (4 * need > r.capacity || r.gen == 0) {
-    size_t cap = (size_t)1 << 20;
+    // (CAPI_LOOPBACK_MIN_RING_MB: diagnostics -- rings that never have to grow)
+    static const size_t floor_ = [] { const char* e = getenv("CAPI_LOOPBACK_MIN_RING_MB"); return e ? (size_t)atol(e) << 20 : (size_t)1 << 20; }();
+    size_t cap = floor_ ? floor_ : (size_t)1 << 20;
     while (cap < 4 * need) cap <<= 1;
     if (cap < r.capacity) cap = r.capacity;
     r.capacity = cap;

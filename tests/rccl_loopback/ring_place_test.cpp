@@ -25,7 +25,7 @@ int main(int argc, char** argv) {
       const size_t off = lb_async::ring_place(s, bytes, ws, gs), off_r = lb_async::ring_place(r, bytes, wr, gr);
       if (off != off_r || gs != gr || s.gen != r.gen) { printf("FAIL: sender and receiver disagree at message %d (seed %u)\n", k, seed); return 1; }
       if (ws > consumed) { consumed = ws; ++waits; }                         // the sender's device-side wait
-      const size_t end = off + ((bytes + 255) & ~(size_t)255);
+      const size_t end = s.live.back().end;
       if (end > s.capacity) { printf("FAIL: message %d leaves the ring (seed %u)\n", k, seed); return 1; }
       for (const Rec& m : sent)
         if (m.seq > consumed && m.gen == s.gen && m.off < end && m.end > off) {

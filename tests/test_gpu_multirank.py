@@ -275,6 +275,8 @@ def test_eight_ranks_as_threads_2x2x2_grid_and_cacqr_3d(oracle, mode):
     and without the chunk pipeline.  Factors against the 1-rank oracle, as in the one-rank-per-process cases."""
     subprocess.check_call(["make", "-C", os.path.dirname(LOOPBACK), "-s"])
     subprocess.check_call(["make", "-C", os.path.dirname(THREAD_DRIVER), "-s"])
+    import torch
+    torch.cuda.empty_cache()          # (the session's earlier tests may have left tens of GiB in this process's caching allocator: the eight ranks share the card)
     world, c, n = 8, 2, 4096
     cases = [
         {"tag": "ch_p0", "kind": "cholinv", "n": n, "c": c, "bc": -3, "ci": 1, "serialize": True, "policy": 0},

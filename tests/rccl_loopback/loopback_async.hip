@@ -20,6 +20,10 @@
 // generation, the receiver maps it).  A ring holds at least four messages of the largest size seen, so a sender only ever waits for
 // the consumption of messages at least three back: inside one ncclGroup at most three messages per (communicator, peer, direction).
 // A watchdog thread ends the process with a diagnosis when device-side waits stop making progress (CAPI_LOOPBACK_TIMEOUT_S).
+// The transport checks ITSELF: every message ends in a trailer (checksum of what the sender put into the ring, length, sequence number, channel identity) that the
+// receiver compares with what it finds before it reports the message consumed (CAPI_LOOPBACK_VERIFY=0 turns that off), and every ring ends in a label the receiver reads
+// back through its mapping when it opens the handle (CAPI_LOOPBACK_LABEL: 0 skips the label, -1 also its 4096 bytes -- diagnostics).  Why: DESIGN.md section 6 (iv).
+// CAPI_LOOPBACK_MIN_RING_MB sets the smallest ring (default 1).
 #include "loopback_async.h"
 #include "ring_place.h"
 

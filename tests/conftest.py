@@ -12,6 +12,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """The multi-process GPU tests run FIRST, while the pytest process itself holds nothing on the card: measured on MI355X (profiles/r4_eight_thread_ranks_2x2x2.txt),
+    the eight-rank rehearsals take 11 / 30 s then, 75 / 62 s after the single-GPU tests have left this process with its session handle, streams and workspace, and
+    116 / 161 s after the full-size tests have grown that workspace -- the ranks' processes share the GPU with whatever their parent keeps on it."""
+    first = [it for it in items if "test_gpu_multirank.py" in it.nodeid]
+    if first:
+        rest = [it for it in items if "test_gpu_multirank.py" not in it.nodeid]
+        items[:] = first + rest
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """CPU oracle (test infrastructure; oracle/capital_oracle.c)."""

@@ -487,6 +487,8 @@ def main():
         m_loc, n5 = QR_CONFIG5_SLICE
         if args.qr_rows:
             m_loc = args.qr_rows
+        elif args.one_device:
+            m_loc //= args.gpus            # a rehearsal's ranks share ONE card's HBM: the slice that fills a GPU is divided among them (its rate says nothing)
         m5 = m_loc * args.gpus
         q5 = time_cacqr2(driver, m5, n5, reps, distributed, device)
         out["cacqr2_config5"] = {"workload": f"CA-CholeskyQR2 m={m5} n={n5} (1-D row blocks, {args.gpus} GPU; per-GPU slice {m_loc} x {n5} of BASELINE config 5"

@@ -65,9 +65,17 @@ def main():
                     p = driver.Cholinv(case["n"], c=case["c"], complete_inv=case["ci"], split=1, bc_mult=case["bc"], layout=case.get("layout", 0),
                                        num_chunks=case.get("chunks", 0), serialize=case["serialize"], bc_policy=case["policy"], trsm_mode=case.get("trsm", False))
                     p.generate()
+                    t0 = time.time()
                     p.factor()
+                    t1 = time.time()
                     p.factor()
                     res = p.residual()
+                    if case.get("light"):            # a large rehearsal (tools/rehearse_config4_grid.py): no factors on disk, their sums and the validator's residual
+                        R = p.R()
+                        np.savez(os.path.join(cfg["dir"], f"{tag}_rank{rank}.npz"), xyz=np.array([p.x, p.y, p.z, p.d, p.c]), residual=res,
+                                 sums=np.array([R.sum(), np.abs(R).sum(), float(np.square(R).sum())]), seconds=np.array([t1 - t0, time.time() - t1]))
+                        p.close()
+                        continue
                     Rinv = p.Rinv() if not case.get("trsm", False) else np.zeros((1, 1))
                     np.savez(os.path.join(cfg["dir"], f"{tag}_rank{rank}.npz"), R=p.R(), Rinv=Rinv, xyz=np.array([p.x, p.y, p.z, p.d, p.c]), residual=res)
                     p.close()

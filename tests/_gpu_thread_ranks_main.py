@@ -85,6 +85,12 @@ def main():
                     q.generate()
                     q.factor()
                     c3 = case.get("c", 1)
+                    if case.get("light"):
+                        R = q.R()
+                        np.savez(os.path.join(cfg["dir"], f"{tag}_rank{rank}.npz"), residual=q.residual(), orth=q.orthogonality(),
+                                 sums=np.array([R.sum(), np.abs(R).sum(), float(np.square(R).sum())]))
+                        q.close()
+                        continue
                     np.savez(os.path.join(cfg["dir"], f"{tag}_rank{rank}.npz"), A=q.A(), Q=q.Q(), R=q.R(),
                              residual=q.residual() if c3 == 1 else -1.0, orth=q.orthogonality() if c3 == 1 else -1.0)
                     q.close()

@@ -1,4 +1,4 @@
-"""Config 4's grid at a size that means something, on ONE MI355X: the 2 x 2 x 2 grid as eight thread-ranks (four processes x two threads, tests/thread_ranks)
+"""Configs 4 and 5 in their own rank counts at a size that means something, on ONE MI355X: the 2 x 2 x 2 grid as eight thread-ranks (four processes x two threads, tests/thread_ranks)
 over the asynchronous loopback transport, n = 16384 by default (every rank's block 8192 x 8192; n = 65536 itself needs eight cards' HBM).  No oracle at this
 size: the reference validator's residual on the grid, and the two depth layers -- which hold the same blocks -- must agree bit for bit in the sums of R.
     python tools/rehearse_config4_grid.py [n] [out.txt]"""
@@ -48,6 +48,21 @@ def main():
             print(f"  {case['tag']:>18}: validator residual {res:.2e}; the depth layers' sums of R are {'bit-identical' if layers_agree else 'DIFFERENT'}; "
                   f"factor() {secs[0]:.2f} s then {secs[1]:.2f} s incl. the residual, processes {wall:.0f} s (eight ranks share the card: not a rate)  {'ok' if good else 'FAILED'}", file=out)
             out.flush()
+    # config 5's shape, CA-CholeskyQR2 with width 1024 in 1-D row blocks over the eight ranks (2^18 rows each here, 2^23 on eight cards): R is replicated -- every
+    # rank must hold the same bits -- and the validators' residual / orthogonality are the reference's
+    m_loc = 1 << 18
+    case = {"tag": "cacqr2_w1024", "kind": "cacqr", "m": m_loc * 8, "n": 1024, "serialize": False, "light": True}
+    with tempfile.TemporaryDirectory() as d:
+        t0 = time.time()
+        T._launch_thread_ranks(4, 2, {"dir": d, "cases": [case]}, "async", timeout=400)
+        wall = time.time() - t0
+        z = [np.load(os.path.join(d, f"{case['tag']}_rank{r}.npz")) for r in range(8)]
+        res, orth = max(float(v["residual"]) for v in z), max(float(v["orth"]) for v in z)
+        same = all(np.array_equal(v["sums"], z[0]["sums"]) for v in z)
+        good = res <= 1e-13 and orth <= 1e-13 and same
+        ok &= good
+        print(f"CA-CholeskyQR2 m = {m_loc * 8} (8 x {m_loc} rows), n = 1024, the same eight ranks: residual {res:.2e}, orthogonality {orth:.2e}; R is "
+              f"{'bit-identical on all eight ranks' if same else 'NOT the same on all ranks'}; processes {wall:.0f} s  {'ok' if good else 'FAILED'}", file=out)
     print("all ok" if ok else "FAILED", file=out)
     sys.exit(0 if ok else 1)
 

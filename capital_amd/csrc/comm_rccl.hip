@@ -302,7 +302,9 @@ int capi_pairs_transfer(capi_comm_t c, const int* dst, const double* send, doubl
     }
     return CAPI_OK;
   }
-  static const int64_t min_count = getenv("CAPITAL_MULTIPATH_MIN") ? atoll(getenv("CAPITAL_MULTIPATH_MIN")) : ((int64_t)1 << 20);
+  // (read per call: tests and A/B tools change it between cases of one process, and every rank of a transfer must cut its message the same way)
+  const char* min_env = getenv("CAPITAL_MULTIPATH_MIN");
+  const int64_t min_count = min_env ? atoll(min_env) : ((int64_t)1 << 20);
   RcclPaths x{c};
   const int rc = pair_paths::transfer(x, c->rank, c->size, dst, send, recv, count, scratch, min_count);
   if (rc < 0) { snprintf(c->h->err, sizeof(c->h->err), "capi_pairs_transfer: invalid transfer set, or scratch missing"); return CAPI_EINVAL; }

@@ -59,6 +59,7 @@ template <bool GIVEN>
 __device__ __forceinline__ void leaf_diag_mfma(double* __restrict__ M, double* __restrict__ Vs, int k, int lane, bool unit,
                                                int* __restrict__ info, int info_base, int b) {
   const int c = lane & 15, g = lane >> 4, k0 = 16 * k;
+  int first_bad = 0;
   d4l_t T, Z;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -90,10 +91,11 @@ __device__ __forceinline__ void leaf_diag_mfma(double* __restrict__ M, double* _
       if (!GIVEN) {
 #pragma unroll
         for (int m = 0; m < s; ++m) p -= l[s][m] * l[s][m];
-        if (!(p > 0.0)) {
-          if (lane == 0 && k0 + kb + s < b) atomicCAS(info, 0, info_base + k0 + kb + s + 1);
-          p = 1.0;
-        }
+        // (branch-free: every lane holds the same p, but the compiler cannot know -- an `if` here is an exec-mask round trip and a taken branch
+        //  on the critical chain of every one of the 16 pivots; the first bad pivot is reported once, behind the tile)
+        const bool bad_p = !(p > 0.0);
+        first_bad = (bad_p && first_bad == 0 && k0 + kb + s < b) ? info_base + k0 + kb + s + 1 : first_bad;
+        p = bad_p ? 1.0 : p;
         // 1/sqrt(p) from v_rsq_f64 + Newton (a few ulp; the IEEE sqrt/div sequences cost ~10x more per step)
         double ys = __builtin_amdgcn_rsq(p);
         ys = ys * (1.5 - 0.5 * p * ys * ys);
@@ -155,6 +157,7 @@ __device__ __forceinline__ void leaf_diag_mfma(double* __restrict__ M, double* _
     M[(k0 + row) + (k0 + c) * LLD] = row <= c ? T[r] : 0.0;      // U, zeros below the diagonal
     Vs[k * 256 + row + c * 16] = c <= row ? Z[r] : 0.0;          // V[row][c], stored [col][row]-major with ld 16
   }
+  if (!GIVEN && first_bad != 0 && lane == 0) atomicCAS(info, 0, first_bad);
 }
 
 // upper triangle of the LDS tile to global (zeros below the diagonal on request): the LDS reads of a round are issued

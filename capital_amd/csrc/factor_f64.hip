@@ -59,7 +59,7 @@ template <bool GIVEN>
 __device__ __forceinline__ void leaf_diag_mfma(double* __restrict__ M, double* __restrict__ Vs, int k, int lane, bool unit,
                                                int* __restrict__ info, int info_base, int b) {
   const int c = lane & 15, g = lane >> 4, k0 = 16 * k;
-  int first_bad = 0;
+  unsigned bad_mask = 0;                                 // bit i: pivot i of this tile was not positive (one bit operation per pivot on the chain; decoded behind the tile)
   d4l_t T, Z;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -94,12 +94,13 @@ __device__ __forceinline__ void leaf_diag_mfma(double* __restrict__ M, double* _
         // (branch-free: every lane holds the same p, but the compiler cannot know -- an `if` here is an exec-mask round trip and a taken branch
         //  on the critical chain of every one of the 16 pivots; the first bad pivot is reported once, behind the tile)
         const bool bad_p = !(p > 0.0);
-        first_bad = (bad_p && first_bad == 0 && k0 + kb + s < b) ? info_base + k0 + kb + s + 1 : first_bad;
+        bad_mask |= bad_p ? 1u << (kb + s) : 0u;
         p = bad_p ? 1.0 : p;
-        // 1/sqrt(p) from v_rsq_f64 + Newton (a few ulp; the IEEE sqrt/div sequences cost ~10x more per step)
+        // 1/sqrt(p): v_rsq_f64 (good to ~2^-23) and ONE third-order step, y (15 - 10 z + 3 z^2) / 8 with z = p y^2 -- error (5/2) e^3, i.e. below 2^-66 before rounding;
+        // five dependent operations instead of the six of two Newton steps (the IEEE sqrt / div sequences cost ~10x more per pivot)
         double ys = __builtin_amdgcn_rsq(p);
-        ys = ys * (1.5 - 0.5 * p * ys * ys);
-        ys = ys * (1.5 - 0.5 * p * ys * ys);
+        const double z = (p * ys) * ys;
+        ys = ys * __builtin_fma(__builtin_fma(0.375, z, -1.25), z, 1.875);
         y[s] = ys;
 #pragma unroll
         for (int a_ = s + 1; a_ < 4; ++a_) {
@@ -157,7 +158,10 @@ __device__ __forceinline__ void leaf_diag_mfma(double* __restrict__ M, double* _
     M[(k0 + row) + (k0 + c) * LLD] = row <= c ? T[r] : 0.0;      // U, zeros below the diagonal
     Vs[k * 256 + row + c * 16] = c <= row ? Z[r] : 0.0;          // V[row][c], stored [col][row]-major with ld 16
   }
-  if (!GIVEN && first_bad != 0 && lane == 0) atomicCAS(info, 0, first_bad);
+  if (!GIVEN && bad_mask != 0 && lane == 0) {
+    const int first = __ffs((int)bad_mask) - 1;
+    if (k0 + first < b) atomicCAS(info, 0, info_base + k0 + first + 1);
+  }
 }
 
 // upper triangle of the LDS tile to global (zeros below the diagonal on request): the LDS reads of a round are issued

@@ -95,12 +95,13 @@ __device__ __forceinline__ void leaf_diag_mfma(double* __restrict__ M, double* _
         //  on the critical chain of every one of the 16 pivots; the first bad pivot is reported once, behind the tile)
         const bool bad_p = !(p > 0.0);
         bad_mask |= bad_p ? 1u << (kb + s) : 0u;
-        p = bad_p ? 1.0 : p;
-        // 1/sqrt(p): v_rsq_f64 (good to ~2^-23) and ONE third-order step, y (15 - 10 z + 3 z^2) / 8 with z = p y^2 -- error (5/2) e^3, i.e. below 2^-66 before rounding;
-        // five dependent operations instead of the six of two Newton steps (the IEEE sqrt / div sequences cost ~10x more per pivot)
+        p = bad_p ? 1.0 : p;                               // (recording without replacing was measured: the shorter chain schedules worse, leaf 86.3 k -> 87.7 k cycles)
+        // 1/sqrt(p): v_rsq_f64 (good to ~2^-23) and ONE third-order step, y (15 - 10 z + 3 z^2) / 8 with z = p y^2, written in the residual e = 1 - z:
+        // y + (y e) (1/2 + 3/8 e) -- error (5/2) e^3, below 2^-66 before rounding; four dependent operations instead of the six of two Newton steps
+        // (the IEEE sqrt / div sequences cost ~10x more per pivot)
         double ys = __builtin_amdgcn_rsq(p);
-        const double z = (p * ys) * ys;
-        ys = ys * __builtin_fma(__builtin_fma(0.375, z, -1.25), z, 1.875);
+        const double e = __builtin_fma(-(p * ys), ys, 1.0);
+        ys = __builtin_fma(ys * e, __builtin_fma(0.375, e, 0.5), ys);
         y[s] = ys;
 #pragma unroll
         for (int a_ = s + 1; a_ < 4; ++a_) {

@@ -55,9 +55,9 @@ __device__ __forceinline__ double readlane_f64(double x, int l) {
 //   4. rows kb..kb+3 of T and Z become Lp and Ep (U's rows, V's rows).
 // The dependency chain is 4 x (four pivots + two MFMA latencies) instead of 16 x (LDS round trip + barrier): ~3k cycles
 // per tile against ~9.5k.  GIVEN: the tile already holds a finished triangular factor U; only V is formed.
-template <bool GIVEN>
+template <bool GIVEN, bool IN_REGS = false>
 __device__ __forceinline__ void leaf_diag_mfma(double* __restrict__ M, double* __restrict__ Vs, int k, int lane, bool unit,
-                                               int* __restrict__ info, int info_base, int b) {
+                                               int* __restrict__ info, int info_base, int b, d4l_t Tin = d4l_t{0.0, 0.0, 0.0, 0.0}) {
   const int c = lane & 15, g = lane >> 4, k0 = 16 * k;
   unsigned bad_mask = 0;                                 // bit i: pivot i of this tile was not positive (one bit operation per pivot on the chain; decoded behind the tile)
   d4l_t T, Z;
@@ -65,10 +65,15 @@ __device__ __forceinline__ void leaf_diag_mfma(double* __restrict__ M, double* _
   for (int r = 0; r < 4; ++r) {
     const int row = g + 4 * r;
     const int lo = row < c ? row : c, hi = row < c ? c : row;
-    double t = M[(k0 + lo) + (k0 + hi) * LLD];           // upper triangle is authoritative: symmetrise on the way in
-    if (GIVEN) {
-      t = row <= c ? M[(k0 + row) + (k0 + c) * LLD] : 0.0;
-      if (unit && row == c) t = 1.0;
+    double t;
+    if (IN_REGS) {
+      t = Tin[r];                                        // the caller's accumulators ARE this layout, and hold both triangles (the diagonal tiles are kept symmetric)
+    } else {
+      t = M[(k0 + lo) + (k0 + hi) * LLD];                // upper triangle is authoritative: symmetrise on the way in
+      if (GIVEN) {
+        t = row <= c ? M[(k0 + row) + (k0 + c) * LLD] : 0.0;
+        if (unit && row == c) t = 1.0;
+      }
     }
     T[r] = t;
     Z[r] = row == c ? 1.0 : 0.0;
@@ -316,7 +321,17 @@ __global__ __launch_bounds__(LEAF_THREADS, 1) void potrf_trtri_leaf128_kernel(do
     __syncthreads();
     LEAF_MARK();
   } else {
-    if (wave == 0) leaf_diag_mfma<false>(M, Vs, 0, lane, false, info, info_base, b);
+    if (wave == 0) {
+      leaf_diag_mfma<false>(M, Vs, 0, lane, false, info, info_base, b);
+    } else {
+      // Meanwhile the idle waves make the OTHER diagonal 16 x 16 tiles symmetric in LDS (the load keeps the upper triangle only; mirrored loads from HBM were
+      // measured: +3.5 k cycles of uncoalesced reads).  Every trailing update of such a tile is a symmetric product, so it stays symmetric, and wave 0 hands the
+      // updated tile to its factorisation in registers -- no store, no symmetrising re-read between two links of the chain.
+      for (int e = tid - 64; e < (nk - 1) * 256; e += LEAF_THREADS - 64) {
+        const int kt = 1 + (e >> 8), i = e & 15, j = (e >> 4) & 15;
+        if (i > j) M[(16 * kt + i) + (16 * kt + j) * LLD] = M[(16 * kt + j) + (16 * kt + i) * LLD];
+      }
+    }
     __syncthreads();
     LEAF_MARK();
     for (int k = 0; k + 1 < nk; ++k) {
@@ -361,8 +376,17 @@ __global__ __launch_bounds__(LEAF_THREADS, 1) void potrf_trtri_leaf128_kernel(do
           }
           return f;
         };
-        const int stride = wave == 0 ? ntiles : LNW - 1;              // wave 0: tile 0 only; waves 1..: tiles 1, 2, ...
-        int t = wave == 0 ? 0 : wave;
+        if (wave == 0) {                                              // tile 0 only = the next diagonal tile, then its factorisation, all in registers
+          const frag f = load(0, 0);
+          d4l_t acc = f.acc, acc2 = {0.0, 0.0, 0.0, 0.0};
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(f.av[0], f.bv[0], acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(f.av[2], f.bv[2], acc2, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(f.av[1], f.bv[1], acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(f.av[3], f.bv[3], acc2, 0, 0, 0);
+          leaf_diag_mfma<false, true>(M, Vs, k + 1, lane, false, info, info_base, b, acc + acc2);
+        }
+        const int stride = LNW - 1;                                   // waves 1..: tiles 1, 2, ...
+        int t = wave == 0 ? ntiles : wave;
         coords(t);
         frag cur;
         if (t < ntiles) cur = load(lo, hi);
@@ -384,7 +408,6 @@ __global__ __launch_bounds__(LEAF_THREADS, 1) void potrf_trtri_leaf128_kernel(do
           cur = nxt;
           t += stride;
         }
-        if (wave == 0) leaf_diag_mfma<false>(M, Vs, k + 1, lane, false, info, info_base, b);   // same wave wrote the tile
       }
       __syncthreads();
       LEAF_MARK();

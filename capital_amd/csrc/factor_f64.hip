@@ -385,8 +385,9 @@ __global__ __launch_bounds__(LEAF_THREADS, 1) void potrf_trtri_leaf128_kernel(do
           acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(f.av[3], f.bv[3], acc2, 0, 0, 0);
           leaf_diag_mfma<false, true>(M, Vs, k + 1, lane, false, info, info_base, b, acc + acc2);
         }
-        const int stride = LNW - 1;                                   // waves 1..: tiles 1, 2, ...
-        int t = wave == 0 ? ntiles : wave;
+        // waves 1, 2, 3, 5, 6, 7 take the other tiles; wave 4 sits on wave 0's SIMD and stays out of its way (the chain's VALU and MFMA issue share that SIMD)
+        const int stride = LNW - 2;
+        int t = (wave == 0 || wave == 4) ? ntiles : (wave < 4 ? wave : wave - 1);
         coords(t);
         frag cur;
         if (t < ntiles) cur = load(lo, hi);

@@ -334,6 +334,7 @@ __global__ __launch_bounds__(LEAF_THREADS, 1) void potrf_trtri_leaf128_kernel(do
     }
     __syncthreads();
     LEAF_MARK();
+    d4l_t next_diag = {0.0, 0.0, 0.0, 0.0};       // wave 0: tile (k+1, k+1) with step k's update, in accumulator layout
     for (int k = 0; k + 1 < nk; ++k) {
       const int k0 = 16 * k;
       // panel: R_kc = V_k * A_kc
@@ -349,6 +350,18 @@ __global__ __launch_bounds__(LEAF_THREADS, 1) void potrf_trtri_leaf128_kernel(do
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) M[(k0 + g + 4 * q) + (c0 + r16) * LLD] = acc[q];
+        if (wave == 0 && c == k + 1) {
+          // Wave 0's first tile is R_k,k+1, all that the update of the NEXT diagonal tile needs -- and as an MFMA operand R[4 st + g][r16] is lane (r16, g), register st:
+          // the accumulators just computed.  The update is done here, while the other waves (two to a SIMD) still work on their panel tiles, instead of behind the barrier.
+          d4l_t u, u2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) u[q] = M[(c0 + g + 4 * q) + (c0 + r16) * LLD];
+          u = __builtin_amdgcn_mfma_f64_16x16x4f64(-acc[0], acc[0], u, 0, 0, 0);
+          u2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-acc[2], acc[2], u2, 0, 0, 0);
+          u = __builtin_amdgcn_mfma_f64_16x16x4f64(-acc[1], acc[1], u, 0, 0, 0);
+          u2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-acc[3], acc[3], u2, 0, 0, 0);
+          next_diag = u + u2;
+        }
       }
       __syncthreads();
       LEAF_MARK();
@@ -376,15 +389,7 @@ __global__ __launch_bounds__(LEAF_THREADS, 1) void potrf_trtri_leaf128_kernel(do
           }
           return f;
         };
-        if (wave == 0) {                                              // tile 0 only = the next diagonal tile, then its factorisation, all in registers
-          const frag f = load(0, 0);
-          d4l_t acc = f.acc, acc2 = {0.0, 0.0, 0.0, 0.0};
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(f.av[0], f.bv[0], acc, 0, 0, 0);
-          acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(f.av[2], f.bv[2], acc2, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(f.av[1], f.bv[1], acc, 0, 0, 0);
-          acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(f.av[3], f.bv[3], acc2, 0, 0, 0);
-          leaf_diag_mfma<false, true>(M, Vs, k + 1, lane, false, info, info_base, b, acc + acc2);
-        }
+        if (wave == 0) leaf_diag_mfma<false, true>(M, Vs, k + 1, lane, false, info, info_base, b, next_diag);   // (updated in the panel phase, still in registers)
         // waves 1, 2, 3, 5, 6, 7 take the other tiles; wave 4 sits on wave 0's SIMD and stays out of its way (the chain's VALU and MFMA issue share that SIMD)
         const int stride = LNW - 2;
         int t = (wave == 0 || wave == 4) ? ntiles : (wave < 4 ? wave : wave - 1);

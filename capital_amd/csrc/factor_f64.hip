@@ -20,15 +20,17 @@ namespace {
 constexpr int LEAF = 128;
 
 // ------------------------------------------------------------------------------------------------------------------
-// MFMA-blocked leaf: one workgroup factors AND inverts a diagonal block of order b <= 128 held in LDS (128 x 130 doubles,
-// leading dimension 130 = 2 mod 32 -> conflict-free ds_read_b64 fragment reads).  Panels are 16 wide (the fp64 MFMA tile):
-//   diag(k)     16 fused steps on the 16x16 diagonal tile, one element per thread, one barrier per step: the right-looking
-//               Cholesky update AND the forward substitution for V = U^-T run together (both need only row s of U);
-//   panel(k)    R_kc = V * A_kc          for the tiles right of the diagonal        (MFMA, tiles dealt to the 4 waves)
-//   trailing(k) A_rc -= R_kr^T * R_kc    for k < r <= c                              (MFMA)
-// then the inverse, block column by block column, in place over the factor (which has already gone to HBM):
-//   W_k = R_kj * X_jj (k < j),  X_ij = -sum_{k=i..j-1} X_ik W_k  (products in registers, barrier, then written),  X_jj = V_j^T.
-// The 16-step diagonal phases are the critical path (~250 cycles a step); everything else is a few hundred MFMAs.
+// MFMA-blocked leaf: one workgroup factors AND inverts a diagonal block of order b <= 128 held in LDS (128 x 129 doubles: an odd
+// leading dimension, 8-byte fragment accesses without bank conflicts).  Panels are 16 wide (the fp64 MFMA tile):
+//   diag(k)     the 16 x 16 diagonal tile, factored and inverted by ONE wave in registers (leaf_diag_mfma: four block steps of width 4);
+//   panel(k)    R_kc = V_k * A_kc        for the tiles right of the diagonal        (MFMA, one tile per wave; wave 0 takes the tile right of the
+//               diagonal and goes on to update the NEXT diagonal tile from that tile's accumulators, keeping the result in registers)
+//   trailing(k) A_rc -= R_kr^T * R_kc    for k < r <= c                              (MFMA; wave 0 factors the next diagonal tile instead, waves 1-3
+//               and 5-7 take the tiles -- wave 4 shares wave 0's SIMD and stays idle)
+// then the inverse by halving, in place over the factor (which has already gone to HBM): X12 = -(X11 R12) X22 at tile-block sizes 1, 2, 4.
+// The chain of the eight diagonal tiles is the critical path: ~4.2 k cycles of one wave's dependent arithmetic per tile (16 pivots: v_rsq_f64 and one
+// third-order correction, column scalings, four MFMA round trips) + a panel phase of 0.65-1.9 k between two tiles; load 7 k, stores 4.3 + 4.2 k,
+// inverse 20 k (its last level bound by the one CU's MFMA rate).  profiles/r4_leaf_branch_free_pivots.txt has the history, cycle by cycle.
 typedef double d4l_t __attribute__((ext_vector_type(4)));
 typedef double d2l_t __attribute__((ext_vector_type(2)));
 #ifndef LEAF_LLD
@@ -44,8 +46,8 @@ __device__ __forceinline__ double readlane_f64(double x, int l) {
   return __hiloint2double(hi, lo);
 }
 
-// The 16 x 16 diagonal tile, factored AND inverted by ONE wave with the tile in MFMA accumulator layout (the other three
-// waves wait at the barrier that follows).  Four block steps of width 4 instead of sixteen scalar steps:
+// The 16 x 16 diagonal tile, factored AND inverted by ONE wave with the tile in MFMA accumulator layout (the other
+// waves work on the trailing tiles meanwhile, or wait at the barrier that follows).  Four block steps of width 4 instead of sixteen scalar steps:
 //   T (symmetric, both triangles kept) and Z (starts as I, ends as V = U^-T) live as D-layout registers: lane (c = l&15,
 //   g = l>>4), register r  <->  element [g + 4r][c].  Rows kb..kb+3 are then register kb/4 -- which, read as an MFMA
 //   operand, is exactly the 16 x 4 panel T[:,kb..kb+3] (by symmetry) resp. Z^T's panel: no data movement at all.
@@ -53,8 +55,9 @@ __device__ __forceinline__ double readlane_f64(double x, int l) {
 //   2. panels   Lp = T[:,kb:kb+4] W^T,  Ep = E[:,kb:kb+4] W^T     one MFMA each  (A = W padded to 16 x 4, B = the register)
 //   3. updates  T -= Lp Lp^T,  Z -= Lp Ep^T                        one MFMA each
 //   4. rows kb..kb+3 of T and Z become Lp and Ep (U's rows, V's rows).
-// The dependency chain is 4 x (four pivots + two MFMA latencies) instead of 16 x (LDS round trip + barrier): ~3k cycles
-// per tile against ~9.5k.  GIVEN: the tile already holds a finished triangular factor U; only V is formed.
+// The dependency chain is 4 x (four pivots + two MFMA latencies) instead of 16 x (LDS round trip + barrier): 4.2 k cycles
+// per tile against ~9.5 k.  GIVEN: the tile already holds a finished triangular factor U; only V is formed.  IN_REGS: the
+// tile arrives in the caller's accumulators (that IS this layout; the caller keeps diagonal tiles symmetric).
 template <bool GIVEN, bool IN_REGS = false>
 __device__ __forceinline__ void leaf_diag_mfma(double* __restrict__ M, double* __restrict__ Vs, int k, int lane, bool unit,
                                                int* __restrict__ info, int info_base, int b, d4l_t Tin = d4l_t{0.0, 0.0, 0.0, 0.0}) {

@@ -262,7 +262,8 @@ def _launch_thread_ranks(nproc, threads, cfg, mode, timeout=int(os.environ.get("
                 p.kill()
     if timed_out:
         outs = [p.communicate()[0] or "" for p in procs]
-    assert not timed_out and all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
+    assert not timed_out and all(p.returncode == 0 for p in procs), \
+        f"exit codes {[p.returncode for p in procs]}{' (timed out)' if timed_out else ''}\n" + "\n".join(o[-3000:] for o in outs)
 
 
 @pytest.mark.parametrize("mode", ["host", "async"])

@@ -26,6 +26,9 @@ def main():
          "env": {"CAPITAL_MULTIPATH": "1"}},
         {"tag": "trsm_mode", "kind": "cholinv", "n": n, "c": 2, "bc": -2, "ci": 0, "serialize": False, "policy": 0, "trsm": True, "light": True},
     ]
+    only = os.environ.get("REHEARSE_ONLY")
+    if only:
+        cases = [c for c in cases if c["tag"] in only.split(",")]
     # one launch per case: the rehearsal's transport keeps its rings to the end of a process (hipFree would drain a sibling rank's stream), and at this size a case's
     # rings are tens of GiB
     ok = True

@@ -51,7 +51,10 @@ N_CHOLESKY = 65536                # BASELINE.json `metric`: Cholesky n = 65536 -
 GRID_C = {1: 1, 2: 2, 4: 1, 8: 2}  # N -> c of the d x d x c grid (d*d*c = N): 1x1x1, 1x1x2, 2x2x1, 2x2x2
 QR_CONFIG3 = (1 << 22, 256)       # BASELINE config 3 (one GPU)
 QR_CONFIG5_SLICE = (1 << 23, 1024)  # rows per GPU and width of BASELINE config 5 (m = 2^26 on 8 GPUs)
-BASE_CASE_ORDER = 1024            # aggregated order of the recursion's base case on every grid
+BASE_CASE_ORDER = 1024            # aggregated order of the recursion's base case on the grids (N > 1: 2 x and 4 x this are probed beside it)
+BASE_CASE_ORDER_ONE_GPU = 2048    # on one GPU: since round 4's work on the diagonal-block routine an order-2048 base case (1.08 ms) beats two of order 1024 plus the products
+                                  # between them; measured on one box each (profiles/r4_base_case_order_one_gpu.txt): n = 65536 1688.9 / 1689.0 -> 1683.3 / 1684.0 ms,
+                                  # n = 32768 236.3-237.1 -> 235.4-235.8 ms; order 4096 and 512 lose
 T_START, BUDGET_S = 0.0, 480.0    # set in main()
 
 
@@ -318,7 +321,7 @@ def main():
     n = args.n or N_CHOLESKY
     c = GRID_C[args.gpus]
     d = int(round((args.gpus // c) ** 0.5))
-    bc = args.bc if args.bc is not None else bc_mult_for(n, d, c, BASE_CASE_ORDER)
+    bc = args.bc if args.bc is not None else bc_mult_for(n, d, c, BASE_CASE_ORDER_ONE_GPU if args.gpus == 1 else BASE_CASE_ORDER)
     # N > 1: how the grid communicates is chosen ON THIS NODE, by measurement.  The plain form -- one RCCL call per
     # pair collective, no overlap -- is timed first, in full (W + K steps): from then on a valid line exists.  Then every other form
     # (multi-path pair transfers over all xGMI links, the chunked SUMMA pipeline on a second stream, both) gets one warm-up and one timed
@@ -449,13 +452,13 @@ def main():
 
     if args.gpus == 1 and not args.no_config2 and not args.n and in_budget("config2", 12 * step_s / 7 + 20):
         n2 = 32768
-        r2 = time_cholesky(driver, L, h, n2, 1, bc_mult_for(n2, 1, 1, BASE_CASE_ORDER), 0, max(args.steps, 3), 1, False, device, bc_policy=2)
+        r2 = time_cholesky(driver, L, h, n2, 1, bc_mult_for(n2, 1, 1, BASE_CASE_ORDER_ONE_GPU), 0, max(args.steps, 3), 1, False, device, bc_policy=2)
         k2 = r2["kernel"]
         out["config2"] = {"workload": f"n={n2} recursive Cholesky with inverse on 1 GPU (BASELINE config 2)", "tflops": r2["tflops"],
                           "ms_per_step": r2["ms_per_step"], "residual": r2["residual"],
                           "roofline_kernel_tflops": k2["iv"]["flops"] / (k2["iv"]["union_ms"] * 1e-3) / 1e12 if k2["iv"]["union_ms"] > 0 else None}
         # BASELINE words config 2 as "panel POTRF + TRSM + trailing SYRK": the same matrix in TRSM mode (R only, no inverse formed)
-        r2t = time_cholesky(driver, L, h, n2, 1, bc_mult_for(n2, 1, 1, BASE_CASE_ORDER), 0, max(args.steps, 3), 1, False, device, bc_policy=2, trsm_mode=True)
+        r2t = time_cholesky(driver, L, h, n2, 1, bc_mult_for(n2, 1, 1, BASE_CASE_ORDER_ONE_GPU), 0, max(args.steps, 3), 1, False, device, bc_policy=2, trsm_mode=True)
         out["config2"]["trsm_mode"] = {"tflops": r2t["tflops"], "ms_per_step": r2t["ms_per_step"], "residual": r2t["residual"]}
 
     if args.gpus == 1 and not args.no_config2 and not args.n and in_budget("cholesky_trsm_mode", 4 * step_s + 15):

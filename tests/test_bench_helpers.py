@@ -21,6 +21,7 @@ def test_grid_and_base_case_rule():
         n_loc = -(-bench.N_CHOLESKY // d)
         assert d * (n_loc // (c * d * 2 ** (-bc))) == bench.BASE_CASE_ORDER, (n_gpus, bc)
     assert bench.bc_mult_for(32768, 1, 1, 1024) == -5 and bench.bc_mult_for(65536, 1, 1, 1024) == -6
+    assert bench.bc_mult_for(65536, 1, 1, bench.BASE_CASE_ORDER_ONE_GPU) == -5 and bench.bc_mult_for(32768, 1, 1, bench.BASE_CASE_ORDER_ONE_GPU) == -4   # one GPU: order 2048
     assert bench.QR_CONFIG5_SLICE[0] * 8 == 1 << 26 and bench.QR_CONFIG5_SLICE[1] == 1024        # N = 8 is BASELINE config 5
 
 
